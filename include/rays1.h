@@ -1,0 +1,227 @@
+/* rays1.h — C-ABI of librays1.so, the MI355X-native replacement for the per-pixel /
+ * per-sample path-tracing hot path of montib/rays1bench `src/step13`.
+ *
+ * The reference has no FFI or plugin interface: its boundary for this path is three
+ * scene builders and one function in a single translation unit
+ *     Scene *create_small_scene()/create_medium_scene()/create_large_scene()
+ *                                      src/step13/rayweek1.cpp:552 / :582 / :654
+ *     RESULT benchmark(Scene*, Pix*, bool write_tga, const char *scene_name)
+ *                                      src/step13/rayweek1.cpp:845
+ * This header is what a maintainer would bind from that function (INTEGRATION.md shows
+ * the patch): plain C, POD structs, caller-owned memory, integer return codes, no
+ * exceptions, no C++/torch types.  `rays1bench_amd/csrc/rayweek1_hip.cpp` is the
+ * drop-in host program built on top of it (same entry points, CLI and output files).
+ *
+ * Threading: one call at a time per context (the reference calls benchmark() serially
+ * from main, rayweek1.cpp:969-984).  All functions return R1_OK (0) or a negative
+ * R1_E* code; r1_last_error() describes the last failure on the calling thread.
+ * There is NO CPU fallback: without a usable HIP device every compute entry point
+ * fails with R1_ENODEVICE.
+ */
+#ifndef RAYS1_H
+#define RAYS1_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define R1_ABI_VERSION 1
+
+enum
+{
+    R1_OK = 0,
+    R1_EINVAL = -1,    /* bad argument (null pointer, non-positive size, bad sharding) */
+    R1_ENODEVICE = -2, /* no HIP device / HIP runtime unusable                        */
+    R1_EHIP = -3,      /* a HIP call failed; see r1_last_error()                      */
+    R1_ENOMEM = -4,    /* device or host allocation failed                            */
+    R1_ELIMIT = -5     /* scene / image exceeds a documented limit                    */
+};
+
+/* Material classes of the reference (rayweek1.cpp:396-511), flattened. */
+enum
+{
+    R1_MAT_LAMBERTIAN = 0, /* albedo                              rayweek1.cpp:396-412 */
+    R1_MAT_METAL = 1,      /* albedo, param = fuzz (<= 1)         rayweek1.cpp:419-436 */
+    R1_MAT_DIELECTRIC = 2, /* param = refraction index            rayweek1.cpp:461-511 */
+    R1_MAT_NONE = 255      /* placeholder sphere (material == nullptr, rayweek1.cpp:574-576) */
+};
+
+/* Mirror of SphereSOA::InstanceData (src/step13/soa_sphere.h:38-53) with the
+ * polymorphic `Material*` column replaced by a flat material table.  `count` includes
+ * the reference's padding placeholders (centre 1e9, inv_radius 0); spheres with
+ * inv_radius == 0 (placeholders AND non-positive radii, soa_sphere.cpp:81) are never
+ * hit, exactly as rayweek1.cpp:291.  All arrays are host memory, length `count`,
+ * owned by the caller and only read during the call they are passed to. */
+typedef struct r1_scene
+{
+    uint32_t count;
+    const float *center_x;
+    const float *center_y;
+    const float *center_z;
+    const float *radius_sq;
+    const float *inv_radius;
+    const uint8_t *mat_type; /* R1_MAT_* */
+    const float *albedo_r;
+    const float *albedo_g;
+    const float *albedo_b;
+    const float *mat_param; /* fuzz (metal) or refraction index (dielectric) */
+} r1_scene;
+
+/* Mirror of struct Camera after Camera::init (rayweek1.cpp:364-395). */
+typedef struct r1_camera
+{
+    float origin[3];
+    float lower_left[3];
+    float horizontal[3];
+    float vertical[3];
+    float u[3];
+    float v[3];
+    float w[3];
+    float lens_radius;
+} r1_camera;
+
+/* Runtime replacements for the reference's compile-time configuration
+ * (src/common/common.h:19-28: SCREEN_W, SCREEN_H, NUM_SAMPLES_PER_PIXEL, MAX_BOUNCES)
+ * plus the build-defined seeding contract (include/rays1_seed.h) and sharding. */
+typedef struct r1_params
+{
+    int32_t width;       /* SCREEN_W                                              */
+    int32_t height;      /* SCREEN_H                                              */
+    int32_t spp;         /* NUM_SAMPLES_PER_PIXEL                                 */
+    int32_t max_bounces; /* MAX_BOUNCES (reference: 50); 1..R1_MAX_BOUNCES_LIMIT  */
+    uint32_t seed;       /* frame seed of the per-sample seeding contract         */
+    int32_t tile_w;      /* tile size for multi-device sharding (reference: 32)   */
+    int32_t tile_h;
+    int32_t shard;       /* this device renders tiles t with t % num_shards == shard */
+    int32_t num_shards;  /* 1 = whole frame                                       */
+    int32_t variant;     /* R1_VARIANT_*; 0 = default kernel                      */
+} r1_params;
+
+#define R1_MAX_BOUNCES_LIMIT 63
+
+enum
+{
+    R1_VARIANT_DEFAULT = 0,   /* fastest validated kernel                                   */
+    R1_VARIANT_REFERENCE = 1, /* pass 1 in the reference's exact arithmetic (rayweek1.cpp:190-202),
+                                 no prefilter; slower, used to cross-check the default       */
+    R1_VARIANT_PREFILTER = 2  /* conservative 8-op prefilter + exact re-test */
+};
+
+typedef struct r1_context r1_context; /* opaque: device, stream, events, workspace */
+
+/* ---- lifetime ------------------------------------------------------------------- */
+
+/* Library ABI version (R1_ABI_VERSION of the build). */
+int r1_abi_version(void);
+
+/* Creates a context on HIP device `device` (stream, timing events, scene + workspace
+ * buffers are cached in it so that the `-n` runs of rayweek1.cpp:969-984 do not pay
+ * context creation inside the timed region).  *out is NULL on failure. */
+int r1_create(int device, r1_context **out);
+void r1_destroy(r1_context *ctx);
+
+/* Text of the last error on this thread ("" if none). Never NULL. */
+const char *r1_last_error(void);
+
+/* Number of visible HIP devices, or a negative R1_E* code. */
+int r1_device_count(void);
+
+/* ---- the hot path ---------------------------------------------------------------- */
+
+/* Uploads (and caches) the scene + camera in the context: builds the device-side
+ * sphere table and material table.  Replaces what benchmark() receives as `Scene*`
+ * (rayweek1.cpp:845, :851). */
+int r1_set_scene(r1_context *ctx, const r1_scene *scene, const r1_camera *camera);
+
+/* Renders the frame (or this shard's tiles of it) and returns everything on the host.
+ * Replaces TileRenderScheduler::run + render_tile (rayweek1.cpp:785-842, :722-782).
+ *   rgb_out      width*height*3 bytes, row-major, row 0 = bottom row, Pix{r,g,b}
+ *                (common.h:80-83, rayweek1.cpp:750); with num_shards > 1 only this
+ *                shard's tiles are written, other bytes are left untouched.
+ *   num_rays_out number of color() invocations (rayweek1.cpp:517) of this shard.
+ *   device_seconds_out  (optional) GPU time of the kernels, from HIP events. */
+int r1_render(r1_context *ctx, const r1_params *params, uint8_t *rgb_out, uint64_t *num_rays_out,
+              double *device_seconds_out);
+
+/* Same, plus the per-sample results the resolve pass sums: samples_out receives
+ * width*height*spp records of 4 floats {r, g, b, bit_cast<float>(uint32 rays)} in the
+ * order ((y*width + x)*spp + s).  For parity tests; whole frame only (num_shards 1). */
+int r1_render_samples(r1_context *ctx, const r1_params *params, uint8_t *rgb_out, uint64_t *num_rays_out,
+                      float *samples_out);
+
+/* ---- device-resident variants (multi-GPU gather, benchmarks) ----------------------- */
+
+/* Number of tiles / bytes of the dense tile block one shard produces for `params`
+ * (every shard's block is padded to the same size so it can be all-gathered). */
+int r1_tile_count(const r1_params *params, int32_t *tiles_total, int32_t *tiles_per_shard);
+size_t r1_shard_block_bytes(const r1_params *params);
+
+/* Enqueues the render of this shard on the context's stream (or on `hip_stream` if
+ * non-NULL, a hipStream_t) and writes DEVICE memory only:
+ *   d_block      r1_shard_block_bytes() bytes: tiles_per_shard tiles of tile_h*tile_w*3
+ *                bytes each, local tile j = global tile shard + j*num_shards
+ *   d_num_rays   one uint64 (overwritten)
+ * Does not synchronise. */
+int r1_render_shard_device(r1_context *ctx, const r1_params *params, void *d_block, void *d_num_rays, void *hip_stream);
+
+/* Scatters `num_shards` gathered blocks (concatenated in shard order, device memory)
+ * into the row-major image d_rgb (width*height*3 bytes, device memory). */
+int r1_assemble_device(r1_context *ctx, const r1_params *params, const void *d_blocks, void *d_rgb, void *hip_stream);
+
+/* Blocks until the context's stream is idle. */
+int r1_sync(r1_context *ctx);
+
+/* HIP-event duration (ms) of the trace kernel / of all kernels of the last render
+ * enqueued through this context (valid after r1_sync or a host-returning call). */
+int r1_last_timing(r1_context *ctx, double *trace_kernel_ms, double *total_ms);
+
+/* Launch geometry and occupancy facts of the last render (for reports). */
+typedef struct r1_launch_info
+{
+    int32_t compute_units;
+    int32_t blocks;
+    int32_t threads_per_block;
+    int32_t spheres_active; /* spheres with inv_radius != 0 that the sweep visits */
+    int32_t spheres_padded; /* `count` of the scene (N_pad of the reference)     */
+    uint64_t samples;       /* pixel-samples traced                              */
+} r1_launch_info;
+int r1_last_launch_info(r1_context *ctx, r1_launch_info *out);
+
+/* ---- host-side helpers of the drop-in (no GPU needed) ------------------------------ */
+
+enum
+{
+    R1_SCENE_SMALL = 0,  /* create_small_scene   rayweek1.cpp:552 */
+    R1_SCENE_MEDIUM = 1, /* create_medium_scene  rayweek1.cpp:582 */
+    R1_SCENE_LARGE = 2,  /* create_large_scene   rayweek1.cpp:654 */
+    R1_SCENE_GRID = 3    /* build-defined: the large generator scaled to grid_w x grid_h spheres */
+};
+
+typedef struct r1_host_scene r1_host_scene; /* owns the arrays an r1_scene points to */
+
+/* Builds one of the reference scenes for an image of width x height (the aspect the
+ * reference takes from SCREEN_W/SCREEN_H, rayweek1.cpp:564).  grid_w/grid_h are only
+ * used by R1_SCENE_GRID (0 = the reference's 30 x 16). */
+int r1_host_scene_create(int kind, int32_t width, int32_t height, int32_t grid_w, int32_t grid_h, r1_host_scene **out);
+void r1_host_scene_destroy(r1_host_scene *hs);
+const r1_scene *r1_host_scene_spheres(const r1_host_scene *hs);
+const r1_camera *r1_host_scene_camera(const r1_host_scene *hs);
+
+/* tga_write_rgb24 (common.h:86-122): writes a 24-bit TGA and, like the reference,
+ * leaves `pixels` with R and B swapped.  Returns R1_OK or R1_EINVAL if the file
+ * cannot be opened. */
+int r1_tga_write_rgb24(const char *filename, int32_t width, int32_t height, uint8_t *pixels);
+
+/* log_results (common.h:47-77): writes out_<scene>.txt as
+ * `version|%.3fs|%llu|%0.3f mrays/s|` averaged over the runs. */
+int r1_log_results(const char *version, const char *scene, const double *elapsed_seconds, const uint64_t *num_rays,
+                   int32_t num_runs);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RAYS1_H */
