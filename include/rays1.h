@@ -178,6 +178,14 @@ int r1_sync(r1_context *ctx);
  * enqueued through this context (valid after r1_sync or a host-returning call). */
 int r1_last_timing(r1_context *ctx, double *trace_kernel_ms, double *total_ms);
 
+/* Per-frame kernel timing over a run of frames: between r1_timing_begin and r1_timing_end
+ * every render enqueued through the context records its own HIP events (on the stream it
+ * is launched on) instead of the single "last frame" set; r1_timing_end waits for them and
+ * returns the summed trace-kernel and trace+resolve durations (ms) and the frame count.
+ * Frames beyond max_frames reuse the last slot. */
+int r1_timing_begin(r1_context *ctx, int32_t max_frames);
+int r1_timing_end(r1_context *ctx, double *trace_ms_sum, double *total_ms_sum, int32_t *frames);
+
 /* Launch geometry and occupancy facts of the last render (for reports). */
 typedef struct r1_launch_info
 {

@@ -1,0 +1,315 @@
+"""ctypes binding of librays1.so (include/rays1.h).  No compute happens in Python and
+nothing here imports oracle/: this is the product's host-side mirror of the reference's
+interface for the hot path (src/step13/rayweek1.cpp:552-719 scene builders, :845 benchmark,
+src/common/common.h:36-122 RESULT / log_results / tga_write_rgb24)."""
+import ctypes as C
+import os
+import subprocess
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+
+R1_OK, R1_EINVAL, R1_ENODEVICE, R1_EHIP, R1_ENOMEM, R1_ELIMIT = 0, -1, -2, -3, -4, -5
+SCENE_SMALL, SCENE_MEDIUM, SCENE_LARGE, SCENE_GRID = 0, 1, 2, 3
+VARIANT_DEFAULT, VARIANT_REFERENCE, VARIANT_PREFILTER = 0, 1, 2
+
+
+class R1Error(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"librays1 error {code}: {text}")
+        self.code = code
+
+
+class CScene(C.Structure):
+    _fields_ = [("count", C.c_uint32)] + [
+        (n, C.POINTER(C.c_float)) for n in ("center_x", "center_y", "center_z", "radius_sq", "inv_radius")
+    ] + [("mat_type", C.POINTER(C.c_uint8))] + [
+        (n, C.POINTER(C.c_float)) for n in ("albedo_r", "albedo_g", "albedo_b", "mat_param")
+    ]
+
+
+class CCamera(C.Structure):
+    _fields_ = [(n, C.c_float * 3) for n in ("origin", "lower_left", "horizontal", "vertical", "u", "v", "w")] + [
+        ("lens_radius", C.c_float)
+    ]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32), ("max_bounces", C.c_int32),
+        ("seed", C.c_uint32), ("tile_w", C.c_int32), ("tile_h", C.c_int32),
+        ("shard", C.c_int32), ("num_shards", C.c_int32), ("variant", C.c_int32),
+    ]
+
+
+class LaunchInfo(C.Structure):
+    _fields_ = [("compute_units", C.c_int32), ("blocks", C.c_int32), ("threads_per_block", C.c_int32),
+                ("spheres_active", C.c_int32), ("spheres_padded", C.c_int32), ("samples", C.c_uint64)]
+
+
+def make_params(width, height, spp, seed=10001, max_bounces=50, tile_w=32, tile_h=32, shard=0, num_shards=1, variant=0):
+    return Params(width, height, spp, max_bounces, seed, tile_w, tile_h, shard, num_shards, variant)
+
+
+def lib_path():
+    return os.path.join(LIBDIR, "librays1.so")
+
+
+def build(verbose=False):
+    """Compiles librays1.so and rayweek1_hip in-tree with hipcc --offload-arch=gfx950."""
+    subprocess.check_call(["make", "-C", CSRC] + ([] if verbose else ["-s"]))
+
+
+_lib = None
+
+# every symbol include/rays1.h declares: (name, restype, argtypes)
+_u8p, _f32p, _u64p, _i32p, _dblp = (C.POINTER(t) for t in (C.c_uint8, C.c_float, C.c_uint64, C.c_int32, C.c_double))
+_ctx = C.c_void_p
+SYMBOLS = [
+    ("r1_abi_version", C.c_int, []),
+    ("r1_create", C.c_int, [C.c_int, C.POINTER(_ctx)]),
+    ("r1_destroy", None, [_ctx]),
+    ("r1_last_error", C.c_char_p, []),
+    ("r1_device_count", C.c_int, []),
+    ("r1_set_scene", C.c_int, [_ctx, C.POINTER(CScene), C.POINTER(CCamera)]),
+    ("r1_render", C.c_int, [_ctx, C.POINTER(Params), _u8p, _u64p, _dblp]),
+    ("r1_render_samples", C.c_int, [_ctx, C.POINTER(Params), _u8p, _u64p, _f32p]),
+    ("r1_tile_count", C.c_int, [C.POINTER(Params), _i32p, _i32p]),
+    ("r1_shard_block_bytes", C.c_size_t, [C.POINTER(Params)]),
+    ("r1_render_shard_device", C.c_int, [_ctx, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("r1_assemble_device", C.c_int, [_ctx, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("r1_sync", C.c_int, [_ctx]),
+    ("r1_last_timing", C.c_int, [_ctx, _dblp, _dblp]),
+    ("r1_timing_begin", C.c_int, [_ctx, C.c_int32]),
+    ("r1_timing_end", C.c_int, [_ctx, _dblp, _dblp, _i32p]),
+    ("r1_last_launch_info", C.c_int, [_ctx, C.POINTER(LaunchInfo)]),
+    ("r1_host_scene_create", C.c_int, [C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    ("r1_host_scene_destroy", None, [C.c_void_p]),
+    ("r1_host_scene_spheres", C.POINTER(CScene), [C.c_void_p]),
+    ("r1_host_scene_camera", C.POINTER(CCamera), [C.c_void_p]),
+    ("r1_tga_write_rgb24", C.c_int, [C.c_char_p, C.c_int32, C.c_int32, _u8p]),
+    ("r1_log_results", C.c_int, [C.c_char_p, C.c_char_p, _dblp, _u64p, C.c_int32]),
+]
+
+
+def lib():
+    """Loads librays1.so (fails loudly if it has not been built: no fallback)."""
+    global _lib
+    if _lib is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise R1Error(R1_ENODEVICE, f"{p} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                        "(there is no CPU fallback)")
+        L = C.CDLL(p)
+        for name, res, args in SYMBOLS:
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != R1_OK:
+        raise R1Error(rc, lib().r1_last_error().decode(errors="replace"))
+
+
+def device_count():
+    n = lib().r1_device_count()
+    return max(n, 0)
+
+
+class Scene:
+    """Host scene = what create_*_scene() returns in the reference (Scene{camera, hitables},
+    rayweek1.cpp:539-549), flattened; owns the native r1_host_scene."""
+
+    def __init__(self, kind, width, height, grid_w=0, grid_h=0, name=None):
+        self._h = C.c_void_p()
+        _check(lib().r1_host_scene_create(kind, width, height, grid_w, grid_h, C.byref(self._h)))
+        self.kind, self.width, self.height = kind, width, height
+        self.name = name or {0: "small", 1: "medium", 2: "large", 3: "grid"}[kind]
+        self.spheres = lib().r1_host_scene_spheres(self._h)
+        self.camera = lib().r1_host_scene_camera(self._h)
+
+    @property
+    def count(self):
+        return int(self.spheres.contents.count)
+
+    def arrays(self):
+        s = self.spheres.contents
+        n = s.count
+        out = {k: np.ctypeslib.as_array(getattr(s, k), shape=(n,)).copy() for k in
+               ("center_x", "center_y", "center_z", "radius_sq", "inv_radius", "albedo_r", "albedo_g", "albedo_b", "mat_param")}
+        out["mat_type"] = np.ctypeslib.as_array(s.mat_type, shape=(n,)).copy()
+        return out
+
+    def camera_array(self):
+        c = self.camera.contents
+        return np.array(sum([list(getattr(c, f)) for f in ("origin", "lower_left", "horizontal", "vertical", "u", "v", "w")], [])
+                        + [c.lens_radius], dtype=np.float32)
+
+    def close(self):
+        if self._h:
+            lib().r1_host_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def create_small_scene(width=1280, height=720):
+    return Scene(SCENE_SMALL, width, height)
+
+
+def create_medium_scene(width=1280, height=720):
+    return Scene(SCENE_MEDIUM, width, height)
+
+
+def create_large_scene(width=1280, height=720):
+    return Scene(SCENE_LARGE, width, height)
+
+
+def create_grid_scene(width, height, grid_w, grid_h):
+    return Scene(SCENE_GRID, width, height, grid_w, grid_h)
+
+
+class Renderer:
+    """One r1_context (device, stream, cached scene + workspace)."""
+
+    def __init__(self, device=0):
+        self._c = _ctx()
+        _check(lib().r1_create(device, C.byref(self._c)))
+        self.device = device
+
+    def set_scene(self, scene):
+        _check(lib().r1_set_scene(self._c, scene.spheres, scene.camera))
+
+    def set_scene_raw(self, cscene, ccamera):
+        _check(lib().r1_set_scene(self._c, C.byref(cscene), C.byref(ccamera)))
+
+    def render(self, params):
+        img = np.zeros((params.height, params.width, 3), np.uint8)
+        rays, secs = C.c_uint64(), C.c_double()
+        _check(lib().r1_render(self._c, C.byref(params), img.ctypes.data_as(_u8p), C.byref(rays), C.byref(secs)))
+        return img, int(rays.value), float(secs.value)
+
+    def render_into(self, params, img):
+        rays, secs = C.c_uint64(), C.c_double()
+        _check(lib().r1_render(self._c, C.byref(params), img.ctypes.data_as(_u8p), C.byref(rays), C.byref(secs)))
+        return int(rays.value), float(secs.value)
+
+    def render_samples(self, params):
+        img = np.zeros((params.height, params.width, 3), np.uint8)
+        samples = np.zeros((params.height * params.width * params.spp, 4), np.float32)
+        rays = C.c_uint64()
+        _check(lib().r1_render_samples(self._c, C.byref(params), img.ctypes.data_as(_u8p), C.byref(rays), samples.ctypes.data_as(_f32p)))
+        return img, int(rays.value), samples
+
+    def render_shard_device(self, params, d_block_ptr, d_rays_ptr, stream_ptr=None):
+        _check(lib().r1_render_shard_device(self._c, C.byref(params), C.c_void_p(d_block_ptr), C.c_void_p(d_rays_ptr),
+                                            C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def assemble_device(self, params, d_blocks_ptr, d_rgb_ptr, stream_ptr=None):
+        _check(lib().r1_assemble_device(self._c, C.byref(params), C.c_void_p(d_blocks_ptr), C.c_void_p(d_rgb_ptr),
+                                        C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def sync(self):
+        _check(lib().r1_sync(self._c))
+
+    def last_timing(self):
+        a, b = C.c_double(), C.c_double()
+        _check(lib().r1_last_timing(self._c, C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
+
+    def timing_begin(self, max_frames):
+        _check(lib().r1_timing_begin(self._c, max_frames))
+
+    def timing_end(self):
+        a, b, n = C.c_double(), C.c_double(), C.c_int32()
+        _check(lib().r1_timing_end(self._c, C.byref(a), C.byref(b), C.byref(n)))
+        return float(a.value), float(b.value), int(n.value)
+
+    def launch_info(self):
+        li = LaunchInfo()
+        _check(lib().r1_last_launch_info(self._c, C.byref(li)))
+        return {k: int(getattr(li, k)) for k, _ in LaunchInfo._fields_}
+
+    def close(self):
+        if self._c:
+            lib().r1_destroy(self._c)
+            self._c = _ctx()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shard_block_bytes(params):
+    return int(lib().r1_shard_block_bytes(C.byref(params)))
+
+
+def tile_count(params):
+    a, b = C.c_int32(), C.c_int32()
+    _check(lib().r1_tile_count(C.byref(params), C.byref(a), C.byref(b)))
+    return int(a.value), int(b.value)
+
+
+class RESULT:
+    """common.h:36-45"""
+
+    def __init__(self, elapsed_seconds=0.0, num_rays=0):
+        self.elapsed_seconds = elapsed_seconds
+        self.num_rays = num_rays
+
+    def get_mrays_per_sec(self):
+        return self.num_rays / self.elapsed_seconds / 1000000.0 if self.elapsed_seconds else 0
+
+
+def benchmark(scene, pixels, write_tga, scene_name, spp=10, seed=10001, renderer=None, quiet=False):
+    """Python twin of RESULT benchmark(Scene*, Pix*, bool, const char*) (rayweek1.cpp:845-927):
+    times dispatch -> pixels + ray count on the host (timer span :848 -> :891), prints the
+    report block (:895-902), consumes the scene (:905) and optionally writes out_<scene>.tga."""
+    own = renderer is None
+    r = renderer or Renderer(0)
+    r.set_scene(scene)
+    p = make_params(scene.width, scene.height, spp, seed)
+    t0 = time.perf_counter()
+    rays, dev_s = r.render_into(p, pixels)
+    res = RESULT(time.perf_counter() - t0, rays)
+    if not quiet:
+        info = r.launch_info()
+        print(scene_name)
+        print("elapsed time:   %.3fs" % res.elapsed_seconds)
+        print("total samples:  %d" % (scene.width * scene.height * spp))
+        print("total rays:     %d" % res.num_rays)
+        print("mrays/s:        %0.2f" % res.get_mrays_per_sec())
+        print("device:         hip:%d, %d CUs, %d workgroups x %d" % (r.device, info["compute_units"], info["blocks"], info["threads_per_block"]))
+        print("device time:    %.3fms" % (dev_s * 1e3))
+        print()
+    scene.close()
+    if write_tga:
+        tga_write_rgb24("out_%s.tga" % scene_name, scene.width, scene.height, pixels)
+    if own:
+        r.close()
+    return res
+
+
+def tga_write_rgb24(filename, width, height, pixels):
+    _check(lib().r1_tga_write_rgb24(filename.encode(), width, height, pixels.ctypes.data_as(_u8p)))
+    return True
+
+
+def log_results(version, scene, results):
+    n = len(results)
+    el = (C.c_double * n)(*[r.elapsed_seconds for r in results])
+    ry = (C.c_uint64 * n)(*[r.num_rays for r in results])
+    _check(lib().r1_log_results(version.encode(), scene.encode(), el, ry, n))

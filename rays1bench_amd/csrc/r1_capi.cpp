@@ -1,0 +1,625 @@
+// r1_capi.cpp — the C-ABI of include/rays1.h on top of the HIP runtime: context, scene
+// upload, launches, timing.  Host code only (the kernels live in r1_kernels.hip).
+//
+// There is no CPU fallback anywhere in this file: without a HIP device every compute
+// entry point returns R1_ENODEVICE / R1_EHIP.
+
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "../../include/rays1.h"
+#include "r1_device.h"
+
+extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int blocks, hipStream_t stream);
+extern "C" hipError_t r1_launch_resolve(const R1ResolveArgs *args, hipStream_t stream);
+extern "C" hipError_t r1_launch_assemble(const void *blocks, void *rgb, int width, int height, int tile_w, int tile_h, int tiles_x,
+                                         int tiles_total, int num_shards, int tiles_per_shard, hipStream_t stream);
+extern "C" hipError_t r1_trace_occupancy(int variant, int *blocks_per_cu);
+extern "C" int r1_params_check(const r1_params *p); // r1_host.cpp
+
+// ---- errors ---------------------------------------------------------------------------------
+
+static thread_local char g_error[512] = "";
+
+extern "C" void r1_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *r1_last_error(void) { return g_error; }
+extern "C" int r1_abi_version(void) { return R1_ABI_VERSION; }
+
+#define R1_HIP(call)                                                                                                   \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        hipError_t e_ = (call);                                                                                        \
+        if (e_ != hipSuccess)                                                                                          \
+        {                                                                                                              \
+            r1_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);                   \
+            return e_ == hipErrorOutOfMemory ? R1_ENOMEM : R1_EHIP;                                                    \
+        }                                                                                                              \
+    } while (0)
+
+// ---- context ----------------------------------------------------------------------------------
+
+struct DevBuf
+{
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct r1_context
+{
+    int device = 0;
+    int cus = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    bool timing_valid = false;
+    // optional per-frame event ring (r1_timing_begin/_end): 3 events per frame
+    std::vector<hipEvent_t> ring;
+    int ring_frames = 0, ring_used = 0;
+    bool ring_on = false;
+
+    // scene
+    DevBuf sweep, exact, shade, mat;
+    uint32_t n_active = 0, n_sweep = 0, n_padded_scene = 0;
+    std::vector<uint32_t> active_to_scene;
+    R1DeviceCamera cam;
+    bool have_scene = false;
+
+    // per-frame workspace
+    DevBuf tile_base, counters, samples, image;
+    std::vector<uint32_t> h_tile_base;
+    r1_params tile_key;
+    bool tile_key_valid = false;
+    uint32_t n_local_tiles = 0, total_samples = 0;
+
+    int occupancy[3] = {0, 0, 0}; // blocks per CU of the trace kernel, by variant
+
+    r1_launch_info info;
+};
+
+static int ensure(DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap && b.p)
+        return R1_OK;
+    if (b.p)
+    {
+        R1_HIP(hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes < 256 ? 256 : bytes;
+    R1_HIP(hipMalloc(&b.p, want));
+    b.cap = want;
+    return R1_OK;
+}
+
+static void release(DevBuf &b)
+{
+    if (b.p)
+        (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+extern "C" int r1_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess)
+    {
+        r1_set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+        return R1_ENODEVICE;
+    }
+    return n;
+}
+
+extern "C" int r1_create(int device, r1_context **out)
+{
+    if (!out)
+        return R1_EINVAL;
+    *out = nullptr;
+    int n = r1_device_count();
+    if (n <= 0)
+    {
+        if (n == 0)
+            r1_set_error("no HIP device visible (librays1 has no CPU fallback)");
+        return R1_ENODEVICE;
+    }
+    if (device < 0 || device >= n)
+    {
+        r1_set_error("device %d out of range (0..%d)", device, n - 1);
+        return R1_EINVAL;
+    }
+    r1_context *c = new (std::nothrow) r1_context();
+    if (!c)
+        return R1_ENOMEM;
+    c->device = device;
+    hipDeviceProp_t prop;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess)
+        e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess)
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess)
+        e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess)
+        e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess)
+        e = hipEventCreate(&c->ev2);
+    if (e != hipSuccess)
+    {
+        r1_set_error("r1_create: %s", hipGetErrorString(e));
+        delete c;
+        return R1_EHIP;
+    }
+    c->cus = prop.multiProcessorCount;
+    memset(&c->info, 0, sizeof(c->info));
+    c->info.compute_units = c->cus;
+    *out = c;
+    return R1_OK;
+}
+
+extern "C" void r1_destroy(r1_context *c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->device);
+    if (c->stream)
+        (void)hipStreamSynchronize(c->stream);
+    release(c->sweep), release(c->exact), release(c->shade), release(c->mat);
+    release(c->tile_base), release(c->counters), release(c->samples), release(c->image);
+    for (hipEvent_t e : c->ring)
+        (void)hipEventDestroy(e);
+    if (c->ev0)
+        (void)hipEventDestroy(c->ev0);
+    if (c->ev1)
+        (void)hipEventDestroy(c->ev1);
+    if (c->ev2)
+        (void)hipEventDestroy(c->ev2);
+    if (c->stream)
+        (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// ---- scene upload -------------------------------------------------------------------------------
+
+// largest float <= v, then one more step down (guards the double->float conversion)
+static float round_down(double v)
+{
+    float f = (float)v;
+    if ((double)f > v)
+        f = nextafterf(f, -INFINITY);
+    return nextafterf(f, -INFINITY);
+}
+
+extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *cam)
+{
+    if (!c || !s || !cam || !s->center_x || !s->center_y || !s->center_z || !s->radius_sq || !s->inv_radius || !s->mat_type ||
+        !s->albedo_r || !s->albedo_g || !s->albedo_b || !s->mat_param)
+    {
+        r1_set_error("r1_set_scene: null argument");
+        return R1_EINVAL;
+    }
+    R1_HIP(hipSetDevice(c->device));
+
+    // active spheres: inv_radius != 0 (rayweek1.cpp:291); order preserved so that ties keep
+    // the earlier index as in the reference's in-order resolve loop
+    c->active_to_scene.clear();
+    for (uint32_t i = 0; i < s->count; ++i)
+        if (s->inv_radius[i] != 0)
+        {
+            if (s->mat_type[i] > R1_MAT_DIELECTRIC)
+            {
+                r1_set_error("r1_set_scene: sphere %u is hittable but has no material", i);
+                return R1_EINVAL;
+            }
+            c->active_to_scene.push_back(i);
+        }
+    const uint32_t na = (uint32_t)c->active_to_scene.size();
+    if (na > R1_MAX_ACTIVE_10BIT)
+    {
+        r1_set_error("r1_set_scene: %u hittable spheres; this build supports up to %d", na, R1_MAX_ACTIVE_10BIT);
+        return R1_ELIMIT;
+    }
+    const uint32_t ns = (na + 7u) & ~7u;
+
+    std::vector<float> sweep(4 * (size_t)(ns ? ns : 8)), exact(4 * (size_t)(na ? na : 1)), shade(4 * (size_t)(na ? na : 1)),
+        mat(2 * (size_t)(na ? na : 1));
+    for (uint32_t a = 0; a < na; ++a)
+    {
+        const uint32_t i = c->active_to_scene[a];
+        const float cx = s->center_x[i], cy = s->center_y[i], cz = s->center_z[i], rsq = s->radius_sq[i];
+        const double c2 = (double)cx * cx + (double)cy * cy + (double)cz * cz;
+        // Kp = (|c|^2 - r^2) - 2^-17 (|c|^2 + r^2), rounded down: see sweep_prefilter
+        const double kp = (c2 - (double)rsq) - ldexp(c2 + (double)rsq, -17) - 1e-30;
+        sweep[4 * a + 0] = cx, sweep[4 * a + 1] = cy, sweep[4 * a + 2] = cz, sweep[4 * a + 3] = round_down(kp);
+        exact[4 * a + 0] = cx, exact[4 * a + 1] = cy, exact[4 * a + 2] = cz, exact[4 * a + 3] = rsq;
+        shade[4 * a + 0] = s->inv_radius[i], shade[4 * a + 1] = s->albedo_r[i], shade[4 * a + 2] = s->albedo_g[i],
+                      shade[4 * a + 3] = s->albedo_b[i];
+        uint32_t type = s->mat_type[i];
+        memcpy(&mat[2 * a], &type, 4);
+        mat[2 * a + 1] = s->mat_param[i];
+    }
+    for (uint32_t a = na; a < (ns ? ns : 8); ++a) // never-candidate padding
+        sweep[4 * a + 0] = sweep[4 * a + 1] = sweep[4 * a + 2] = 0, sweep[4 * a + 3] = INFINITY;
+
+    int rc;
+    if ((rc = ensure(c->sweep, sweep.size() * 4)) || (rc = ensure(c->exact, exact.size() * 4)) ||
+        (rc = ensure(c->shade, shade.size() * 4)) || (rc = ensure(c->mat, mat.size() * 4)))
+        return rc;
+    R1_HIP(hipStreamSynchronize(c->stream));
+    R1_HIP(hipMemcpy(c->sweep.p, sweep.data(), sweep.size() * 4, hipMemcpyHostToDevice));
+    R1_HIP(hipMemcpy(c->exact.p, exact.data(), exact.size() * 4, hipMemcpyHostToDevice));
+    R1_HIP(hipMemcpy(c->shade.p, shade.data(), shade.size() * 4, hipMemcpyHostToDevice));
+    R1_HIP(hipMemcpy(c->mat.p, mat.data(), mat.size() * 4, hipMemcpyHostToDevice));
+
+    c->n_active = na;
+    c->n_sweep = ns;
+    c->n_padded_scene = s->count;
+    memcpy(c->cam.origin, cam->origin, 12);
+    memcpy(c->cam.lower_left, cam->lower_left, 12);
+    memcpy(c->cam.horizontal, cam->horizontal, 12);
+    memcpy(c->cam.vertical, cam->vertical, 12);
+    memcpy(c->cam.u, cam->u, 12);
+    memcpy(c->cam.v, cam->v, 12);
+    c->cam.lens_radius = cam->lens_radius;
+    c->have_scene = true;
+    return R1_OK;
+}
+
+// ---- per-frame setup ------------------------------------------------------------------------------
+
+static bool same_tiling(const r1_params &a, const r1_params &b)
+{
+    return a.width == b.width && a.height == b.height && a.spp == b.spp && a.tile_w == b.tile_w && a.tile_h == b.tile_h &&
+           a.shard == b.shard && a.num_shards == b.num_shards;
+}
+
+static int prepare_tiles(r1_context *c, const r1_params *p, hipStream_t st)
+{
+    if (c->tile_key_valid && same_tiling(c->tile_key, *p))
+        return R1_OK;
+    const int tiles_x = (p->width + p->tile_w - 1) / p->tile_w;
+    const int tiles_y = (p->height + p->tile_h - 1) / p->tile_h;
+    const int total = tiles_x * tiles_y;
+    c->h_tile_base.clear();
+    uint64_t acc = 0;
+    for (int t = p->shard; t < total; t += p->num_shards)
+    {
+        const int x0 = (t % tiles_x) * p->tile_w, y0 = (t / tiles_x) * p->tile_h;
+        const int tw = p->tile_w < p->width - x0 ? p->tile_w : p->width - x0;
+        const int th = p->tile_h < p->height - y0 ? p->tile_h : p->height - y0;
+        c->h_tile_base.push_back((uint32_t)acc);
+        acc += (uint64_t)tw * th * p->spp;
+    }
+    c->n_local_tiles = (uint32_t)c->h_tile_base.size();
+    c->h_tile_base.push_back((uint32_t)acc);
+    c->total_samples = (uint32_t)acc;
+    int rc = ensure(c->tile_base, c->h_tile_base.size() * 4);
+    if (rc)
+        return rc;
+    R1_HIP(hipStreamSynchronize(st));
+    R1_HIP(hipMemcpy(c->tile_base.p, c->h_tile_base.data(), c->h_tile_base.size() * 4, hipMemcpyHostToDevice));
+    c->tile_key = *p;
+    c->tile_key_valid = true;
+    return R1_OK;
+}
+
+// Enqueues trace + resolve on `st`. out/d_rays are device pointers.
+static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int block_layout, void *d_rays, hipStream_t st)
+{
+    if (!c->have_scene)
+    {
+        r1_set_error("no scene set (call r1_set_scene first)");
+        return R1_EINVAL;
+    }
+    int rc = r1_params_check(p);
+    if (rc)
+        return rc;
+    const int variant = p->variant == R1_VARIANT_REFERENCE ? 1 : 2;
+    R1_HIP(hipSetDevice(c->device));
+    if ((rc = prepare_tiles(c, p, st)))
+        return rc;
+    if ((rc = ensure(c->counters, 64)))
+        return rc;
+    if ((rc = ensure(c->samples, (size_t)(c->total_samples ? c->total_samples : 1) * 16)))
+        return rc;
+
+    R1TraceArgs a;
+    memset(&a, 0, sizeof(a));
+    a.scene.sweep = (const float4 *)c->sweep.p;
+    a.scene.exact = (const float4 *)c->exact.p;
+    a.scene.shade = (const float4 *)c->shade.p;
+    a.scene.mat = (const float2 *)c->mat.p;
+    a.scene.n_active = c->n_active;
+    a.scene.n_sweep = c->n_sweep;
+    a.cam = c->cam;
+    a.width = p->width, a.height = p->height, a.spp = p->spp, a.max_bounces = p->max_bounces;
+    a.seed = p->seed;
+    a.inv_w = 1.0f / p->width;  // Vec3 inv_image_size(1.0f / td.image_w, 1.0f / td.image_h, 0) rayweek1.cpp:746
+    a.inv_h = 1.0f / p->height;
+    a.tile_w = p->tile_w, a.tile_h = p->tile_h;
+    a.tiles_x = (p->width + p->tile_w - 1) / p->tile_w;
+    a.shard = p->shard, a.num_shards = p->num_shards;
+    a.n_local_tiles = c->n_local_tiles;
+    a.tile_sample_base = (const uint32_t *)c->tile_base.p;
+    a.total_samples = c->total_samples;
+    a.queue = (uint32_t *)c->counters.p;
+    a.samples = (float4 *)c->samples.p;
+    a.num_rays = (unsigned long long *)d_rays;
+
+    if (c->occupancy[variant] == 0)
+        R1_HIP(r1_trace_occupancy(variant, &c->occupancy[variant]));
+    int per_cu = c->occupancy[variant];
+    if (per_cu < 1)
+        per_cu = 1;
+    if (per_cu > 8)
+        per_cu = 8;
+    long long blocks = (long long)c->cus * per_cu;
+    const long long needed = ((long long)c->total_samples + R1_BLOCK - 1) / R1_BLOCK;
+    if (blocks > needed)
+        blocks = needed;
+    if (blocks < 1)
+        blocks = 1;
+
+    hipEvent_t e0 = c->ev0, e1 = c->ev1, e2 = c->ev2;
+    if (c->ring_on && c->ring_frames > 0)
+    {
+        const int slot = c->ring_used < c->ring_frames ? c->ring_used : c->ring_frames - 1;
+        e0 = c->ring[3 * slot], e1 = c->ring[3 * slot + 1], e2 = c->ring[3 * slot + 2];
+        if (c->ring_used < c->ring_frames)
+            ++c->ring_used;
+    }
+    R1_HIP(hipMemsetAsync(c->counters.p, 0, 64, st));
+    R1_HIP(hipMemsetAsync(d_rays, 0, 8, st));
+    R1_HIP(hipEventRecord(e0, st));
+    if (c->total_samples)
+        R1_HIP(r1_launch_trace(&a, variant, (int)blocks, st));
+    R1_HIP(hipEventRecord(e1, st));
+
+    R1ResolveArgs r;
+    memset(&r, 0, sizeof(r));
+    r.samples = (const float4 *)c->samples.p;
+    r.tile_sample_base = (const uint32_t *)c->tile_base.p;
+    r.width = p->width, r.height = p->height, r.spp = p->spp;
+    r.tile_w = p->tile_w, r.tile_h = p->tile_h, r.tiles_x = a.tiles_x;
+    r.shard = p->shard, r.num_shards = p->num_shards;
+    r.n_local_tiles = c->n_local_tiles;
+    r.inv_spp = (float)(1.0f / p->spp); // rayweek1.cpp:765
+    r.out = (uint8_t *)d_out;
+    r.block_layout = block_layout;
+    if (c->n_local_tiles)
+        R1_HIP(r1_launch_resolve(&r, st));
+    R1_HIP(hipEventRecord(e2, st));
+    c->timing_valid = !c->ring_on;
+
+    c->info.blocks = (int32_t)blocks;
+    c->info.threads_per_block = R1_BLOCK;
+    c->info.spheres_active = (int32_t)c->n_active;
+    c->info.spheres_padded = (int32_t)c->n_padded_scene;
+    c->info.samples = c->total_samples;
+    return R1_OK;
+}
+
+// ---- public render entry points ---------------------------------------------------------------------
+
+static int render_host(r1_context *c, const r1_params *p, uint8_t *rgb_out, uint64_t *num_rays_out, double *device_seconds_out,
+                       float *samples_out)
+{
+    if (!c || !p || !rgb_out)
+    {
+        r1_set_error("r1_render: null argument");
+        return R1_EINVAL;
+    }
+    int rc = r1_params_check(p);
+    if (rc)
+        return rc;
+    if (samples_out && p->num_shards != 1)
+    {
+        r1_set_error("r1_render_samples needs num_shards == 1");
+        return R1_EINVAL;
+    }
+    R1_HIP(hipSetDevice(c->device));
+    const bool sharded = p->num_shards > 1;
+    const size_t img_bytes = (size_t)p->width * p->height * 3;
+    const size_t out_bytes = sharded ? r1_shard_block_bytes(p) : img_bytes;
+    if ((rc = ensure(c->image, out_bytes + 64)))
+        return rc;
+    if ((rc = ensure(c->counters, 64)))
+        return rc;
+    void *d_rays = (char *)c->counters.p + 32;
+    if ((rc = enqueue_frame(c, p, c->image.p, sharded ? 1 : 0, d_rays, c->stream)))
+        return rc;
+
+    uint64_t rays = 0;
+    if (!sharded)
+    {
+        R1_HIP(hipMemcpyAsync(rgb_out, c->image.p, img_bytes, hipMemcpyDeviceToHost, c->stream));
+        R1_HIP(hipMemcpyAsync(&rays, d_rays, 8, hipMemcpyDeviceToHost, c->stream));
+        R1_HIP(hipStreamSynchronize(c->stream));
+    }
+    else
+    {
+        std::vector<uint8_t> block(out_bytes);
+        R1_HIP(hipMemcpyAsync(block.data(), c->image.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
+        R1_HIP(hipMemcpyAsync(&rays, d_rays, 8, hipMemcpyDeviceToHost, c->stream));
+        R1_HIP(hipStreamSynchronize(c->stream));
+        const int tiles_x = (p->width + p->tile_w - 1) / p->tile_w;
+        for (uint32_t lt = 0; lt < c->n_local_tiles; ++lt)
+        {
+            const int t = p->shard + (int)lt * p->num_shards;
+            const int x0 = (t % tiles_x) * p->tile_w, y0 = (t / tiles_x) * p->tile_h;
+            const int tw = p->tile_w < p->width - x0 ? p->tile_w : p->width - x0;
+            const int th = p->tile_h < p->height - y0 ? p->tile_h : p->height - y0;
+            for (int ly = 0; ly < th; ++ly)
+                memcpy(rgb_out + ((size_t)(y0 + ly) * p->width + x0) * 3,
+                       block.data() + ((size_t)lt * p->tile_h * p->tile_w + (size_t)ly * p->tile_w) * 3, (size_t)tw * 3);
+        }
+    }
+    if (num_rays_out)
+        *num_rays_out = rays;
+    if (device_seconds_out)
+    {
+        float ms = 0;
+        R1_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev2));
+        *device_seconds_out = ms * 1e-3;
+    }
+    if (samples_out)
+    {
+        // device order is tile-major (tile, pixel-in-tile, sample); the ABI order is
+        // ((y*width + x)*spp + s)
+        std::vector<float> tmp((size_t)c->total_samples * 4);
+        R1_HIP(hipMemcpy(tmp.data(), c->samples.p, tmp.size() * 4, hipMemcpyDeviceToHost));
+        const int tiles_x = (p->width + p->tile_w - 1) / p->tile_w;
+        for (uint32_t lt = 0; lt < c->n_local_tiles; ++lt)
+        {
+            const int x0 = ((int)lt % tiles_x) * p->tile_w, y0 = ((int)lt / tiles_x) * p->tile_h;
+            const int tw = p->tile_w < p->width - x0 ? p->tile_w : p->width - x0;
+            const int th = p->tile_h < p->height - y0 ? p->tile_h : p->height - y0;
+            const float *src = tmp.data() + (size_t)c->h_tile_base[lt] * 4;
+            for (int ly = 0; ly < th; ++ly)
+                for (int lx = 0; lx < tw; ++lx)
+                    memcpy(samples_out + (((size_t)(y0 + ly) * p->width + (x0 + lx)) * p->spp) * 4,
+                           src + ((size_t)(ly * tw + lx) * p->spp) * 4, (size_t)p->spp * 16);
+        }
+    }
+    return R1_OK;
+}
+
+extern "C" int r1_render(r1_context *c, const r1_params *p, uint8_t *rgb_out, uint64_t *num_rays_out, double *device_seconds_out)
+{
+    return render_host(c, p, rgb_out, num_rays_out, device_seconds_out, nullptr);
+}
+
+extern "C" int r1_render_samples(r1_context *c, const r1_params *p, uint8_t *rgb_out, uint64_t *num_rays_out, float *samples_out)
+{
+    if (!samples_out)
+    {
+        r1_set_error("r1_render_samples: null samples_out");
+        return R1_EINVAL;
+    }
+    return render_host(c, p, rgb_out, num_rays_out, nullptr, samples_out);
+}
+
+extern "C" int r1_render_shard_device(r1_context *c, const r1_params *p, void *d_block, void *d_num_rays, void *hip_stream)
+{
+    if (!c || !p || !d_block || !d_num_rays)
+    {
+        r1_set_error("r1_render_shard_device: null argument");
+        return R1_EINVAL;
+    }
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    return enqueue_frame(c, p, d_block, 1, d_num_rays, st);
+}
+
+extern "C" int r1_assemble_device(r1_context *c, const r1_params *p, const void *d_blocks, void *d_rgb, void *hip_stream)
+{
+    if (!c || !p || !d_blocks || !d_rgb)
+    {
+        r1_set_error("r1_assemble_device: null argument");
+        return R1_EINVAL;
+    }
+    int32_t total = 0, per = 0;
+    int rc = r1_tile_count(p, &total, &per);
+    if (rc)
+        return rc;
+    R1_HIP(hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    const int tiles_x = (p->width + p->tile_w - 1) / p->tile_w;
+    R1_HIP(r1_launch_assemble(d_blocks, d_rgb, p->width, p->height, p->tile_w, p->tile_h, tiles_x, total, p->num_shards, per, st));
+    return R1_OK;
+}
+
+extern "C" int r1_sync(r1_context *c)
+{
+    if (!c)
+        return R1_EINVAL;
+    R1_HIP(hipSetDevice(c->device));
+    R1_HIP(hipStreamSynchronize(c->stream));
+    return R1_OK;
+}
+
+extern "C" int r1_last_timing(r1_context *c, double *trace_kernel_ms, double *total_ms)
+{
+    if (!c || !c->timing_valid)
+    {
+        r1_set_error("r1_last_timing: nothing rendered yet");
+        return R1_EINVAL;
+    }
+    R1_HIP(hipEventSynchronize(c->ev2));
+    float a = 0, b = 0;
+    R1_HIP(hipEventElapsedTime(&a, c->ev0, c->ev1));
+    R1_HIP(hipEventElapsedTime(&b, c->ev0, c->ev2));
+    if (trace_kernel_ms)
+        *trace_kernel_ms = a;
+    if (total_ms)
+        *total_ms = b;
+    return R1_OK;
+}
+
+extern "C" int r1_timing_begin(r1_context *c, int32_t max_frames)
+{
+    if (!c || max_frames < 1 || max_frames > 100000)
+    {
+        r1_set_error("r1_timing_begin: bad argument");
+        return R1_EINVAL;
+    }
+    R1_HIP(hipSetDevice(c->device));
+    while ((int)c->ring.size() < 3 * max_frames)
+    {
+        hipEvent_t e;
+        R1_HIP(hipEventCreate(&e));
+        c->ring.push_back(e);
+    }
+    c->ring_frames = max_frames;
+    c->ring_used = 0;
+    c->ring_on = true;
+    return R1_OK;
+}
+
+extern "C" int r1_timing_end(r1_context *c, double *trace_ms_sum, double *total_ms_sum, int32_t *frames)
+{
+    if (!c || !c->ring_on)
+    {
+        r1_set_error("r1_timing_end without r1_timing_begin");
+        return R1_EINVAL;
+    }
+    c->ring_on = false;
+    double a = 0, b = 0;
+    for (int i = 0; i < c->ring_used; ++i)
+    {
+        float x = 0, y = 0;
+        R1_HIP(hipEventSynchronize(c->ring[3 * i + 2]));
+        R1_HIP(hipEventElapsedTime(&x, c->ring[3 * i], c->ring[3 * i + 1]));
+        R1_HIP(hipEventElapsedTime(&y, c->ring[3 * i], c->ring[3 * i + 2]));
+        a += x, b += y;
+    }
+    if (trace_ms_sum)
+        *trace_ms_sum = a;
+    if (total_ms_sum)
+        *total_ms_sum = b;
+    if (frames)
+        *frames = c->ring_used;
+    return R1_OK;
+}
+
+extern "C" int r1_last_launch_info(r1_context *c, r1_launch_info *out)
+{
+    if (!c || !out)
+        return R1_EINVAL;
+    *out = c->info;
+    return R1_OK;
+}

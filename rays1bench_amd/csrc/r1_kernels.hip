@@ -1,0 +1,573 @@
+// r1_kernels.hip — hand-written HIP for gfx950 (MI355X, wave64): the per-pixel/per-sample
+// path-tracing hot path of rays1bench step13.
+//
+// What it replaces (all /root/reference/src/step13/):
+//   render_tile's pixel x sample loop      rayweek1.cpp:722-782   -> r1_trace_kernel + r1_resolve_kernel
+//   Camera::getRay / random_in_unit_disk   rayweek1.cpp:381-386 / :353-362
+//   color() bounce recursion               rayweek1.cpp:515-536   -> flattened register loop
+//   Hitable::hit (AVX2 sweep + resolve)    rayweek1.cpp:152-339   -> sweep_prefilter / sweep_reference
+//   Lambertian/Metal/Dielectric::scatter   rayweek1.cpp:403-409 / :427-433 / :470-511
+//   TileRenderScheduler (atomic tile pop)  rayweek1.cpp:785-842   -> persistent waves + global sample queue
+//
+// Design (DESIGN.md has the long form):
+//   * one LANE per live path; a wave keeps all 64 lanes busy by refilling finished lanes
+//     from a global sample queue (chunks of R1_CHUNK samples per atomic), so the bounce-count
+//     divergence of color() (1..51 rays per sample) costs no lanes;
+//   * the sphere table is wave-uniform: it is read with SCALAR loads (s_load_dwordx4..x16
+//     into SGPRs) and fed to the VALU as SGPR operands — no LDS round trip, no VGPRs;
+//   * pass 1 is an 8-instruction conservative prefilter (7 FMA + 1 compare per ray-sphere
+//     test, vs 11 in the reference's form); candidates are re-tested afterwards in the
+//     reference's exact arithmetic, lane-parallel, from a per-lane LDS list, so results are
+//     bit-identical to the reference's candidate rule (sign bit of its discriminant);
+//   * attenuation is applied in the reference's right-nested order a0*(a1*(...*sky)) by
+//     keeping the hit indices of a path in a packed per-lane LDS stack;
+//   * per-sample radiance goes to HBM (16 B/sample) and a second kernel sums the samples of
+//     a pixel in sample order — the reference's order — which keeps pixels deterministic.
+//
+// Arithmetic contract: identical operation order to oracle/r1_oracle.c (which is pinned to
+// the reference bit-for-bit); no implicit FMA contraction; IEEE sqrt and division.  The only
+// known difference is powf(x,5) (glibc, <1 ulp) vs an exactly rounded x^5 here.
+
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+
+#include "r1_device.h"
+#include "../../include/rays1_seed.h"
+
+#pragma clang fp contract(off)
+
+namespace
+{
+
+struct V3
+{
+    float x, y, z;
+};
+
+// read-only tables are addressed through the constant address space so that a wave-uniform
+// index turns into scalar loads (SMEM) instead of vector loads
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef const f4 __attribute__((address_space(4))) *cf4_ptr;
+
+__device__ __forceinline__ V3 mk(float x, float y, float z)
+{
+    V3 r;
+    r.x = x, r.y = y, r.z = z;
+    return r;
+}
+__device__ __forceinline__ V3 vadd(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 vsub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 vscale(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 vneg(V3 a) { return mk(-a.x, -a.y, -a.z); }
+// mymath.h:205-207: sum(a*b) = (x + y) + z
+__device__ __forceinline__ float vdot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// mymath.h:211: v * (1.0f / length(v)); Ray::Ray normalises every direction (rayweek1.cpp:107)
+__device__ __forceinline__ V3 vunit(V3 v) { return vscale(v, __fdiv_rn(1.0f, __fsqrt_rn(vdot(v, v)))); }
+__device__ __forceinline__ V3 ld3(const float *p) { return mk(p[0], p[1], p[2]); }
+
+// mymath.h:17-25
+__device__ __forceinline__ uint32_t xorshift32(uint32_t &state)
+{
+    uint32_t x = state;
+    x ^= x << 13;
+    x ^= x >> 17;
+    x ^= x << 15;
+    state = x;
+    return x;
+}
+// mymath.h:27-35 and the x4 forms :41-73 — all exact: a 24-bit integer times a power of two
+__device__ __forceinline__ float rand01(uint32_t &s) { return (float)(xorshift32(s) & 0xFFFFFFu) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ float rand02(uint32_t &s) { return (float)(xorshift32(s) & 0xFFFFFFu) * (1.0f / 8388608.0f); }
+
+struct Path
+{
+    V3 o, d;                        // Ray::_origin, Ray::_dir (unit)
+    uint32_t s_scalar, s0, s1, s2;  // ThreadData::state, lanes 0..2 of ThreadData::state4
+    uint32_t k;                     // local sample index (output slot)
+    uint32_t rays;                  // color() invocations of this sample
+    int depth;                      // color()'s depth argument
+    int sp;                         // entries on the attenuation stack
+};
+
+// mymath.h:224-235
+__device__ __forceinline__ V3 random_in_unit_sphere(Path &p)
+{
+    V3 r;
+    do
+    {
+        float a = rand02(p.s0), b = rand02(p.s1), c = rand02(p.s2);
+        r = vsub(mk(a, b, c), mk(1.0f, 1.0f, 1.0f));
+    } while (vdot(r, r) >= 1);
+    return r;
+}
+
+// exactly rounded x^5 (the reference calls powf(x, 5), rayweek1.cpp:458)
+__device__ __forceinline__ float pow5(float x)
+{
+    double d = (double)x;
+    double d2 = d * d;
+    return (float)(d2 * d2 * d);
+}
+
+// ---- the exact ray/sphere test: pass 1 + pass 2 of Hitable::hit for ONE sphere -----------
+// rayweek1.cpp:192-202 (co, nb, c, discr with the reference's two FMA chains), :204 (sign
+// bit), :294-313 (roots, strict compares, t_max shrinks).  Candidates must be presented in
+// increasing index order (ties keep the earlier sphere).
+__device__ __forceinline__ void exact_test(const f4 e, uint32_t idx, const V3 o, const V3 d, float &t_max, int &hit_index)
+{
+    const float cox = e.x - o.x;
+    const float coy = e.y - o.y;
+    const float coz = e.z - o.z;
+    const float nb = __fmaf_rn(coz, d.z, __fmaf_rn(coy, d.y, cox * d.x));
+    const float c = __fmaf_rn(coz, coz, __fmaf_rn(coy, coy, cox * cox)) - e.w;
+    const float discr = nb * nb - c;
+    if (!(__float_as_uint(discr) >> 31))
+    {
+        const float discr_sq = __fsqrt_rn(discr);
+        float temp = nb - discr_sq;
+        if (temp < t_max && temp > 0.001f)
+        {
+            t_max = temp;
+            hit_index = (int)idx;
+        }
+        else
+        {
+            temp = nb + discr_sq;
+            if (temp < t_max && temp > 0.001f)
+            {
+                t_max = temp;
+                hit_index = (int)idx;
+            }
+        }
+    }
+}
+
+// ---- sweep, reference form: every active sphere through exact_test ------------------------
+__device__ __forceinline__ void sweep_reference(const R1DeviceScene &S, const V3 o, const V3 d, float &t_max, int &hit_index)
+{
+    const cf4_ptr tab = (cf4_ptr)S.exact;
+    for (uint32_t i = 0; i < S.n_active; ++i)
+        exact_test(tab[i], i, o, d, t_max, hit_index); // uniform index => scalar loads
+}
+
+// ---- sweep, prefilter form -----------------------------------------------------------------
+// For unit d:  discr = (co.d)^2 - |co|^2 + r^2  with co = c - o
+//            = (c.d - o.d)^2 - (|o|^2 - 2 c.o) - (|c|^2 - r^2)
+// Per ray:    negod = -(o.d), m2o = -2 o, oo' = |o|^2 (1 - 2^-17)
+// Per sphere: Kp = (|c|^2 - r^2) - 2^-17 (|c|^2 + r^2), rounded down          (host, r1_capi.cpp)
+// Test:       fma(nb', nb', -t') >= Kp   with two 3-FMA chains nb', t'        => 7 FMA + 1 compare
+// The slack 2^-17 (|c|^2 + r^2 + |o|^2) exceeds the worst-case fp32 error of BOTH this form and
+// the reference's form, so every sphere whose reference discriminant has a
+// clear sign bit is flagged here; exact_test then applies the reference's own rule.
+__device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const V3 o, const V3 d, float &t_max, int &hit_index,
+                                                uint16_t *cand /* [R1_CAND_CAP][R1_BLOCK] */, const int tid)
+{
+    const float negod = -__fmaf_rn(o.z, d.z, __fmaf_rn(o.y, d.y, o.x * d.x));
+    const float oo = __fmaf_rn(o.z, o.z, __fmaf_rn(o.y, o.y, o.x * o.x));
+    const float oo_adj = __fmaf_rn(oo, -0x1p-17f, oo);
+    const float mx = -2.0f * o.x, my = -2.0f * o.y, mz = -2.0f * o.z;
+
+    int cnt = 0;
+    // constant address space + wave-uniform index => s_load_dwordx4..x16 into SGPRs
+    const cf4_ptr tab = (cf4_ptr)S.sweep;
+    for (uint32_t i = 0; i < S.n_sweep; i += 8)
+    {
+        bool c[8];
+        unsigned long long any = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+        {
+            const f4 s = tab[i + u];
+            const float nb = __fmaf_rn(s.z, d.z, __fmaf_rn(s.y, d.y, __fmaf_rn(s.x, d.x, negod)));
+            const float t = __fmaf_rn(s.z, mz, __fmaf_rn(s.y, my, __fmaf_rn(s.x, mx, oo_adj)));
+            const float q = __fmaf_rn(nb, nb, -t);
+            c[u] = q >= s.w;
+            any |= __ballot(c[u]);
+        }
+        if (any) // wave-uniform: scalar branch
+        {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c[u])
+                {
+                    if (cnt < R1_CAND_CAP)
+                        cand[cnt * R1_BLOCK + tid] = (uint16_t)(i + u);
+                    ++cnt;
+                }
+        }
+    }
+    if (cnt <= R1_CAND_CAP)
+    {
+        for (int j = 0; j < cnt; ++j)
+        {
+            const uint32_t idx = cand[j * R1_BLOCK + tid];
+            exact_test(((const f4 *)S.exact)[idx], idx, o, d, t_max, hit_index);
+        }
+    }
+    else
+    {
+        // more candidates than LDS slots (a ray skimming a row of spheres): exact sweep
+        const cf4_ptr tabx = (cf4_ptr)S.exact;
+        for (uint32_t i = 0; i < S.n_active; ++i)
+            exact_test(tabx[i], i, o, d, t_max, hit_index);
+    }
+}
+
+// packed attenuation stack: three 10-bit sphere indices per LDS word
+__device__ __forceinline__ void stack_push(uint32_t *stack, int tid, int sp, uint32_t idx)
+{
+    const int w = sp / 3, sh = (sp - 3 * w) * 10;
+    uint32_t v = stack[w * R1_BLOCK + tid];
+    v = (v & ~(0x3FFu << sh)) | (idx << sh);
+    stack[w * R1_BLOCK + tid] = v;
+}
+__device__ __forceinline__ uint32_t stack_get(const uint32_t *stack, int tid, int e)
+{
+    const int w = e / 3, sh = (e - 3 * w) * 10;
+    return (stack[w * R1_BLOCK + tid] >> sh) & 0x3FFu;
+}
+
+// k (local sample index) -> pixel, sample; then seeds + primary ray (rayweek1.cpp:759-760)
+__device__ __forceinline__ void start_sample(const R1TraceArgs &A, Path &p, uint32_t k)
+{
+    // tile lookup: largest j with base[j] <= k
+    uint32_t lo = 0, hi = A.n_local_tiles;
+    while (hi - lo > 1)
+    {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (A.tile_sample_base[mid] <= k)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const uint32_t tile = (uint32_t)A.shard + lo * (uint32_t)A.num_shards;
+    const int x0 = (int)(tile % (uint32_t)A.tiles_x) * A.tile_w;
+    const int y0 = (int)(tile / (uint32_t)A.tiles_x) * A.tile_h;
+    const int tw = min(A.tile_w, A.width - x0);
+    const uint32_t r = k - A.tile_sample_base[lo];
+    const uint32_t pix = r / (uint32_t)A.spp;
+    const uint32_t s = r - pix * (uint32_t)A.spp;
+    const int ly = (int)(pix / (uint32_t)tw);
+    const int x = x0 + (int)(pix - (uint32_t)ly * (uint32_t)tw);
+    const int y = y0 + ly;
+
+    const r1_sample_seed sd = r1_seed_sample(A.seed, (uint32_t)(y * A.width + x), s);
+    p.s_scalar = sd.scalar;
+    p.s0 = sd.lane0;
+    p.s1 = sd.lane1;
+    p.s2 = sd.lane2;
+    p.k = k;
+    p.rays = 0;
+    p.depth = 0;
+    p.sp = 0;
+
+    // uv = (myrand01_x4(state4) + (x, y)) * (1/W, 1/H): lanes 0,1 used, lane 2 advances too
+    const float j0 = rand01(p.s0), j1 = rand01(p.s1);
+    (void)xorshift32(p.s2);
+    const float u = (j0 + (float)x) * A.inv_w;
+    const float v = (j1 + (float)y) * A.inv_h;
+
+    // random_in_unit_disk (rayweek1.cpp:353-362): g++ argument order => y gets the first draw
+    V3 dk;
+    do
+    {
+        const float first = rand02(p.s_scalar);
+        const float second = rand02(p.s_scalar);
+        dk = vsub(mk(second, first, 0.0f), mk(1.0f, 1.0f, 0.0f));
+    } while (vdot(dk, dk) >= 1.0f);
+
+    // Camera::getRay (rayweek1.cpp:381-386)
+    const V3 rd = vscale(dk, A.cam.lens_radius);
+    const V3 offset = vadd(vscale(ld3(A.cam.u), rd.x), vscale(ld3(A.cam.v), rd.y));
+    const V3 org = ld3(A.cam.origin);
+    p.o = vadd(org, offset);
+    const V3 dir =
+        vsub(vsub(vadd(vadd(ld3(A.cam.lower_left), vscale(ld3(A.cam.horizontal), u)), vscale(ld3(A.cam.vertical), v)), org), offset);
+    p.d = vunit(dir);
+}
+
+} // namespace
+
+// ============================================================================================
+// The trace kernel.  Persistent: grid = CUs x blocks/CU, every wave loops until the global
+// sample queue is empty and its own lanes have finished their paths.
+// ============================================================================================
+template <int VARIANT>
+__global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
+{
+    __shared__ uint32_t s_stack[R1_STACK_WORDS * R1_BLOCK];
+    __shared__ uint16_t s_cand[R1_CAND_CAP * R1_BLOCK];
+
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+
+    Path p;
+    p.o = mk(0, 0, 0), p.d = mk(0, 0, 0);
+    p.s_scalar = p.s0 = p.s1 = p.s2 = 1;
+    p.k = 0, p.rays = 0, p.depth = 0, p.sp = 0;
+    bool alive = false;
+    unsigned long long lane_rays = 0;
+
+    // wave-uniform queue state
+    uint32_t q_next = 0, q_end = 0;
+    bool exhausted = false;
+
+    for (;;)
+    {
+        // ---- refill finished lanes from the wave's chunk of the global sample queue ----
+        unsigned long long need = __ballot(!alive);
+        while (need)
+        {
+            if (q_next == q_end)
+            {
+                if (exhausted)
+                    break;
+                uint32_t base = 0;
+                if (lane == 0)
+                    base = atomicAdd(A.queue, (uint32_t)R1_CHUNK);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= A.total_samples)
+                {
+                    exhausted = true;
+                    break;
+                }
+                q_next = base;
+                q_end = min(base + (uint32_t)R1_CHUNK, A.total_samples);
+            }
+            const uint32_t avail = q_end - q_next;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            if (!alive && rank < avail)
+            {
+                start_sample(A, p, q_next + rank);
+                alive = true;
+            }
+            q_next += min((uint32_t)__popcll(need), avail);
+            need = __ballot(!alive);
+        }
+        if (__ballot(alive) == 0ull)
+            break;
+
+        if (alive)
+        {
+            // ---- one color() level: count, hit test (rayweek1.cpp:517-519) ----
+            ++p.rays;
+            float t_hit = FLT_MAX;
+            int hit = -1;
+            if (VARIANT == 1)
+                sweep_reference(A.scene, p.o, p.d, t_hit, hit);
+            else
+                sweep_prefilter(A.scene, p.o, p.d, t_hit, hit, s_cand, tid);
+
+            bool done = false;
+            V3 col = mk(0, 0, 0);
+            if (hit >= 0)
+            {
+                if (p.depth < A.max_bounces)
+                {
+                    // hit record (rayweek1.cpp:316-322)
+                    const float4 e = A.scene.exact[hit];
+                    const float4 sh = A.scene.shade[hit];
+                    const float2 mt = A.scene.mat[hit];
+                    const V3 hp = vadd(p.o, vscale(p.d, t_hit));
+                    const V3 n = vscale(vsub(hp, mk(e.x, e.y, e.z)), sh.x);
+                    const uint32_t type = __float_as_uint(mt.x);
+                    if (type == 0u)
+                    {
+                        // Lambertian::scatter rayweek1.cpp:403-409
+                        const V3 target = vadd(vadd(hp, n), random_in_unit_sphere(p));
+                        p.d = vunit(vsub(target, hp));
+                        p.o = hp;
+                        stack_push(s_stack, tid, p.sp, (uint32_t)hit);
+                        ++p.sp;
+                    }
+                    else if (type == 1u)
+                    {
+                        // Metal::scatter rayweek1.cpp:427-433; reflect :414-417
+                        const V3 refl = vsub(p.d, vscale(n, 2.0f * vdot(p.d, n)));
+                        const V3 nd = vunit(vadd(refl, vscale(random_in_unit_sphere(p), mt.y)));
+                        p.o = hp;
+                        p.d = nd;
+                        if (vdot(nd, n) > 0)
+                        {
+                            stack_push(s_stack, tid, p.sp, (uint32_t)hit);
+                            ++p.sp;
+                        }
+                        else
+                            done = true; // scatter() == false -> Vec3(0,0,0), rayweek1.cpp:528
+                    }
+                    else
+                    {
+                        // Dielectric::scatter rayweek1.cpp:470-511 (attenuation 1: nothing to push)
+                        const float ref_idx = mt.y;
+                        const float ddn = vdot(p.d, n);
+                        const V3 reflected = vsub(p.d, vscale(n, 2.0f * ddn));
+                        V3 outward;
+                        float ni_over_nt, cosine;
+                        if (ddn > 0)
+                        {
+                            outward = vneg(n);
+                            ni_over_nt = ref_idx;
+                            cosine = ref_idx * ddn;
+                        }
+                        else
+                        {
+                            outward = n;
+                            ni_over_nt = __fdiv_rn(1.0f, ref_idx);
+                            cosine = -ddn;
+                        }
+                        // refract rayweek1.cpp:439-452
+                        const float dt = vdot(p.d, outward);
+                        const float discriminant = 1.0f - ni_over_nt * ni_over_nt * (1.0f - dt * dt);
+                        float reflect_prob = 1.0f;
+                        V3 refracted = mk(0, 0, 0);
+                        if (discriminant > 0)
+                        {
+                            refracted = vsub(vscale(vsub(p.d, vscale(outward, dt)), ni_over_nt), vscale(outward, __fsqrt_rn(discriminant)));
+                            // schlick rayweek1.cpp:454-459
+                            float r0 = __fdiv_rn(1.0f - ref_idx, 1.0f + ref_idx);
+                            r0 = r0 * r0;
+                            reflect_prob = r0 + (1.0f - r0) * pow5(1.0f - cosine);
+                        }
+                        const V3 nd = (rand01(p.s_scalar) < reflect_prob) ? reflected : refracted;
+                        p.o = hp;
+                        p.d = vunit(nd);
+                    }
+                    ++p.depth;
+                }
+                else
+                    done = true; // depth == MAX_BOUNCES: no scatter, no draws, black (rayweek1.cpp:523-528)
+            }
+            else
+            {
+                // miss: sky (rayweek1.cpp:532-534), lerp = (1 - t) * a + t * b (mymath.h:212-216)
+                const float t = 0.5f * (p.d.y + 1.0f);
+                const float omt = 1.0f - t;
+                col = mk(omt * 1.0f + t * 0.5f, omt * 1.0f + t * 0.7f, omt * 1.0f + t * 1.0f);
+                // unwind: attenuation * color(...) innermost first (rayweek1.cpp:525)
+                for (int e = p.sp - 1; e >= 0; --e)
+                {
+                    const float4 sh = A.scene.shade[stack_get(s_stack, tid, e)];
+                    col = mk(sh.y * col.x, sh.z * col.y, sh.w * col.z);
+                }
+                done = true;
+            }
+            if (done)
+            {
+                A.samples[p.k] = make_float4(col.x, col.y, col.z, __uint_as_float(p.rays));
+                lane_rays += p.rays;
+                alive = false;
+            }
+        }
+    }
+
+    // ray count: wave reduction, one atomic per wave (rayweek1.cpp:809-813)
+    for (int off = 32; off > 0; off >>= 1)
+        lane_rays += __shfl_down(lane_rays, off, 64);
+    if (lane == 0 && lane_rays)
+        atomicAdd(A.num_rays, lane_rays);
+}
+
+template __global__ void r1_trace_kernel<1>(const R1TraceArgs);
+template __global__ void r1_trace_kernel<2>(const R1TraceArgs);
+
+// ============================================================================================
+// Resolve: one thread per pixel of this shard; sums the spp samples in sample order and
+// quantises exactly as rayweek1.cpp:765-775.
+// ============================================================================================
+__global__ void __launch_bounds__(256) r1_resolve_kernel(const R1ResolveArgs A)
+{
+    const uint32_t tiles_stride = gridDim.y;
+    for (uint32_t lt = blockIdx.y; lt < A.n_local_tiles; lt += tiles_stride)
+    {
+        const uint32_t tile = (uint32_t)A.shard + lt * (uint32_t)A.num_shards;
+        const int x0 = (int)(tile % (uint32_t)A.tiles_x) * A.tile_w;
+        const int y0 = (int)(tile / (uint32_t)A.tiles_x) * A.tile_h;
+        const int tw = min(A.tile_w, A.width - x0);
+        const int th = min(A.tile_h, A.height - y0);
+        const uint32_t base = A.tile_sample_base[lt];
+        for (uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x; pix < (uint32_t)(tw * th); pix += gridDim.x * blockDim.x)
+        {
+            const float4 *s = A.samples + base + pix * (uint32_t)A.spp;
+            float cr = 0, cg = 0, cb = 0;
+            for (int i = 0; i < A.spp; ++i)
+            {
+                const float4 v = s[i];
+                cr += v.x, cg += v.y, cb += v.z; // col += color(...) rayweek1.cpp:762
+            }
+            cr *= A.inv_spp, cg *= A.inv_spp, cb *= A.inv_spp;
+            cr = __fsqrt_rn(cr), cg = __fsqrt_rn(cg), cb = __fsqrt_rn(cb);
+            const uint8_t r = (uint8_t)(int)(cr * 255.99f);
+            const uint8_t g = (uint8_t)(int)(cg * 255.99f);
+            const uint8_t b = (uint8_t)(int)(cb * 255.99f);
+            const int ly = (int)(pix / (uint32_t)tw);
+            const int lx = (int)(pix - (uint32_t)ly * (uint32_t)tw);
+            size_t o;
+            if (A.block_layout)
+                o = ((size_t)lt * A.tile_h * A.tile_w + (size_t)ly * A.tile_w + lx) * 3;
+            else
+                o = ((size_t)(y0 + ly) * A.width + (x0 + lx)) * 3;
+            A.out[o + 0] = r;
+            A.out[o + 1] = g;
+            A.out[o + 2] = b;
+        }
+    }
+}
+
+// Scatter gathered dense tile blocks (shard-major) into a row-major image.
+__global__ void __launch_bounds__(256)
+    r1_assemble_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ rgb, int width, int height, int tile_w, int tile_h,
+                       int tiles_x, int tiles_total, int num_shards, int tiles_per_shard)
+{
+    const size_t n = (size_t)width * height;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    {
+        const int y = (int)(i / (size_t)width), x = (int)(i - (size_t)y * width);
+        const int tile = (y / tile_h) * tiles_x + (x / tile_w);
+        const int shard = tile % num_shards, lt = tile / num_shards;
+        const size_t src = (((size_t)shard * tiles_per_shard + lt) * tile_h * tile_w + (size_t)(y % tile_h) * tile_w + (x % tile_w)) * 3;
+        rgb[3 * i + 0] = blocks[src + 0];
+        rgb[3 * i + 1] = blocks[src + 1];
+        rgb[3 * i + 2] = blocks[src + 2];
+    }
+    (void)tiles_total;
+}
+
+// ---- launchers (called from r1_capi.cpp) -----------------------------------------------------
+
+extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int blocks, hipStream_t stream)
+{
+    if (variant == 1)
+        hipLaunchKernelGGL(r1_trace_kernel<1>, dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
+    else
+        hipLaunchKernelGGL(r1_trace_kernel<2>, dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t r1_launch_resolve(const R1ResolveArgs *args, hipStream_t stream)
+{
+    const int tile_pix = args->tile_w * args->tile_h;
+    const int bx = (tile_pix + 255) / 256;
+    const int by = (int)(args->n_local_tiles < 65535u ? args->n_local_tiles : 65535u);
+    hipLaunchKernelGGL(r1_resolve_kernel, dim3(bx, by), dim3(256), 0, stream, *args);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t r1_launch_assemble(const void *blocks, void *rgb, int width, int height, int tile_w, int tile_h, int tiles_x,
+                                         int tiles_total, int num_shards, int tiles_per_shard, hipStream_t stream)
+{
+    const size_t n = (size_t)width * height;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 8192)
+        grid = 8192;
+    hipLaunchKernelGGL(r1_assemble_kernel, dim3(grid), dim3(256), 0, stream, (const uint8_t *)blocks, (uint8_t *)rgb, width, height,
+                       tile_w, tile_h, tiles_x, tiles_total, num_shards, tiles_per_shard);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t r1_trace_occupancy(int variant, int *blocks_per_cu)
+{
+    if (variant == 1)
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<1>, R1_BLOCK, 0);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<2>, R1_BLOCK, 0);
+}

@@ -1,0 +1,205 @@
+// rayweek1_hip.cpp — the drop-in host program: the reference's entry points for the hot path
+//     Scene *create_small_scene() / create_medium_scene() / create_large_scene()
+//                                       (/root/reference/src/step13/rayweek1.cpp:552 / :582 / :654)
+//     RESULT benchmark(Scene *scene, Pix *pixels, bool write_tga, const char *scene_name)
+//                                       (rayweek1.cpp:845-927)
+//     main: -w, -n N                    (rayweek1.cpp:930-988)
+// kept with the same signatures, ownership (benchmark() deletes the scene it is given,
+// rayweek1.cpp:905), stdout block (:895-902), out_<scene>.txt (common.h:47-77) and TGA
+// (common.h:86-122), but rendering through librays1.so (include/rays1.h) on a MI355X.
+//
+// What the reference fixes at compile time (common.h:19-28) is a run-time option here:
+//     --width W --height H --spp S --seed N --device D --variant V
+// Defaults are the reference's multi-threaded defaults: 1280x720, 250 spp.
+
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+
+#include "../../include/rays1.h"
+
+// ---- common.h types ----------------------------------------------------------------------------
+
+struct RESULT // common.h:36-45
+{
+    double elapsed_seconds;
+    uint64_t num_rays;
+    double get_mrays_per_sec() const { return elapsed_seconds ? (num_rays / elapsed_seconds / 1000000.0) : 0; }
+};
+
+struct Pix // common.h:80-83
+{
+    uint8_t r, g, b;
+};
+
+// ---- run-time configuration (the reference's SCREEN_W / SCREEN_H / NUM_SAMPLES_PER_PIXEL) --------
+
+static int g_screen_w = 1280;
+static int g_screen_h = 720;
+static int g_spp = 10 * 25;
+static int g_max_bounces = 50;
+static uint32_t g_seed = 10001;
+static int g_device = 0;
+static int g_variant = R1_VARIANT_DEFAULT;
+static r1_context *g_ctx = nullptr;
+
+// ---- Scene ---------------------------------------------------------------------------------------
+
+class Scene // rayweek1.cpp:539-549: owns its spheres/materials, deleted by benchmark()
+{
+  public:
+    r1_host_scene *host = nullptr;
+    const r1_scene *hitables = nullptr;
+    const r1_camera *camera = nullptr;
+    ~Scene() { r1_host_scene_destroy(host); }
+};
+
+static Scene *make_scene(int kind)
+{
+    Scene *s = new Scene;
+    if (r1_host_scene_create(kind, g_screen_w, g_screen_h, 0, 0, &s->host) != R1_OK)
+    {
+        fprintf(stderr, "scene build failed: %s\n", r1_last_error());
+        exit(1);
+    }
+    s->hitables = r1_host_scene_spheres(s->host);
+    s->camera = r1_host_scene_camera(s->host);
+    return s;
+}
+
+Scene *create_small_scene() { return make_scene(R1_SCENE_SMALL); }
+Scene *create_medium_scene() { return make_scene(R1_SCENE_MEDIUM); }
+Scene *create_large_scene() { return make_scene(R1_SCENE_LARGE); }
+
+// ---- benchmark -------------------------------------------------------------------------------------
+
+RESULT benchmark(Scene *scene, Pix *pixels, bool write_tga, const char *scene_name)
+{
+    RESULT result = {0, 0};
+    auto t0 = std::chrono::high_resolution_clock::now(); // Timer, rayweek1.cpp:848
+
+    r1_params p;
+    memset(&p, 0, sizeof(p));
+    p.width = g_screen_w, p.height = g_screen_h, p.spp = g_spp, p.max_bounces = g_max_bounces;
+    p.seed = g_seed;
+    p.tile_w = 32, p.tile_h = 32; // rayweek1.cpp:855-856
+    p.shard = 0, p.num_shards = 1;
+    p.variant = g_variant;
+
+    double device_seconds = 0;
+    int rc = r1_set_scene(g_ctx, scene->hitables, scene->camera);
+    if (rc == R1_OK)
+        rc = r1_render(g_ctx, &p, &pixels[0].r, &result.num_rays, &device_seconds);
+    if (rc != R1_OK)
+    {
+        // the reference has no error convention: report and return RESULT{0,0}
+        fprintf(stderr, "%s: render failed (%d): %s\n", scene_name, rc, r1_last_error());
+        result.num_rays = 0;
+        delete scene;
+        return result;
+    }
+    result.elapsed_seconds = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count(); // :891
+
+    r1_launch_info li;
+    memset(&li, 0, sizeof(li));
+    r1_last_launch_info(g_ctx, &li);
+    uint64_t total_samples = (uint64_t)g_screen_w * g_screen_h * g_spp;
+
+    printf("%s\n", scene_name);
+    printf("elapsed time:   %.3fs\n", result.elapsed_seconds);
+    printf("total samples:  %llu\n", (unsigned long long)total_samples);
+    printf("total rays:     %llu\n", (unsigned long long)result.num_rays);
+    printf("mrays/s:        %0.2f\n", result.get_mrays_per_sec());
+    printf("device:         hip:%d %d CUs, %d workgroups x %d threads\n", g_device, li.compute_units, li.blocks, li.threads_per_block);
+    printf("device time:    %.3fms (%0.2f mrays/s)\n", device_seconds * 1e3, device_seconds ? result.num_rays / device_seconds / 1e6 : 0.0);
+    printf("\n");
+
+    delete scene; // rayweek1.cpp:905
+
+    if (write_tga)
+    {
+        char filename[128];
+        snprintf(filename, sizeof(filename), "out_%s.tga", scene_name);
+        r1_tga_write_rgb24(filename, g_screen_w, g_screen_h, &pixels[0].r); // swaps R/B in `pixels`, as the reference
+    }
+    return result;
+}
+
+static void log_results(const char *version, const char *scene, const RESULT *results, int num_runs) // common.h:47-77
+{
+    double el[32];
+    uint64_t rays[32];
+    for (int i = 0; i < num_runs; ++i)
+        el[i] = results[i].elapsed_seconds, rays[i] = results[i].num_rays;
+    r1_log_results(version, scene, el, rays, num_runs);
+}
+
+int main(int argc, const char *argv[])
+{
+    bool write_tga = false;
+    int num_runs = 1;
+    const static int MAX_NUMS = 32;
+    RESULT results[MAX_NUMS];
+
+    for (int i = 1; i < argc; ++i)
+    {
+        if (strcmp(argv[i], "-w") == 0)
+            write_tga = true;
+        else if (strcmp(argv[i], "-n") == 0 && i + 1 < argc)
+        {
+            int n = atoi(argv[++i]);
+            if (n >= 1 && n < MAX_NUMS)
+                num_runs = n;
+            else
+                printf("Invalid num_runs parameter: %d\n", n);
+        }
+        else if (strcmp(argv[i], "--width") == 0 && i + 1 < argc)
+            g_screen_w = atoi(argv[++i]);
+        else if (strcmp(argv[i], "--height") == 0 && i + 1 < argc)
+            g_screen_h = atoi(argv[++i]);
+        else if (strcmp(argv[i], "--spp") == 0 && i + 1 < argc)
+            g_spp = atoi(argv[++i]);
+        else if (strcmp(argv[i], "--seed") == 0 && i + 1 < argc)
+            g_seed = (uint32_t)strtoul(argv[++i], 0, 0);
+        else if (strcmp(argv[i], "--device") == 0 && i + 1 < argc)
+            g_device = atoi(argv[++i]);
+        else if (strcmp(argv[i], "--variant") == 0 && i + 1 < argc)
+            g_variant = atoi(argv[++i]);
+    }
+    if (g_screen_w <= 0 || g_screen_h <= 0 || g_spp <= 0)
+    {
+        fprintf(stderr, "bad --width/--height/--spp\n");
+        return 1;
+    }
+
+    // HIP context creation stays outside the timed region and is shared by all -n runs
+    if (r1_create(g_device, &g_ctx) != R1_OK)
+    {
+        fprintf(stderr, "cannot create HIP context: %s\n", r1_last_error());
+        return 2;
+    }
+
+    Pix *pixels = new Pix[(size_t)g_screen_w * g_screen_h];
+    memset(pixels, 0, (size_t)g_screen_w * g_screen_h * sizeof(pixels[0]));
+
+    const char *version = "hip";
+
+    for (int i = 0; i < num_runs; ++i)
+        results[i] = benchmark(create_small_scene(), pixels, write_tga, "small");
+    log_results(version, "small", results, num_runs);
+
+    for (int i = 0; i < num_runs; ++i)
+        results[i] = benchmark(create_medium_scene(), pixels, write_tga, "medium");
+    log_results(version, "medium", results, num_runs);
+
+    for (int i = 0; i < num_runs; ++i)
+        results[i] = benchmark(create_large_scene(), pixels, write_tga, "large");
+    log_results(version, "large", results, num_runs);
+
+    delete[] pixels;
+    r1_destroy(g_ctx);
+    return 0;
+}

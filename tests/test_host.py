@@ -1,0 +1,133 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every symbol
+include/rays1.h declares, the scene builders reproduce the reference's scenes bit-for-bit
+(fixtures dumped from the reference by oracle/gen_golden.py), output formats match
+common.h, and compute entry points fail loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import rays1bench_amd as r1
+from rays1bench_amd import binding
+import r1o
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "rays1.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(r1_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    L = r1.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/rays1.h but not exported"
+    assert declared == {s[0] for s in binding.SYMBOLS}
+    assert L.r1_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    # sizes the C compiler gives the PODs of rays1.h (pointers 8 B, 4-byte scalars)
+    assert C.sizeof(binding.CScene) == 8 + 10 * 8
+    assert C.sizeof(binding.CCamera) == 22 * 4
+    assert C.sizeof(binding.Params) == 10 * 4
+    assert C.sizeof(r1o.Scene) == C.sizeof(binding.CScene)
+    assert C.sizeof(r1o.Params) == C.sizeof(binding.Params)
+
+
+SIZES = {"small": [(1200, 800), (1280, 720), (200, 100), (80, 60), (70, 50)],
+         "medium": [(1200, 800), (1280, 720), (200, 100), (80, 60), (77, 45)],
+         "large": [(1200, 800), (1280, 720), (200, 100), (80, 60), (1920, 1080), (320, 200)]}
+
+
+@pytest.mark.parametrize("name", ["small", "medium", "large"])
+def test_scene_builders_match_reference_bitwise(name):
+    make = {"small": r1.create_small_scene, "medium": r1.create_medium_scene, "large": r1.create_large_scene}[name]
+    for (w, h) in SIZES[name]:
+        g = r1o.read_golden(os.path.join(GOLD, f"scene_{name}_{w}x{h}.bin"))
+        sc = make(w, h)
+        a = sc.arrays()
+        assert sc.count == int(g["dims"][2]) == {"small": 8, "medium": 48, "large": 488}[name]
+        for gk, fk in r1o.GOLD_TO_FIELD.items():
+            assert a[fk].tobytes() == g[gk].tobytes(), (name, w, h, fk)
+        assert sc.camera_array().tobytes() == g["camera"].tobytes(), (name, w, h)
+        sc.close()
+
+
+def test_large_scene_facts_from_survey():
+    sc = r1.create_large_scene(1200, 800)
+    a = sc.arrays()
+    assert (a["center_x"][0], a["center_z"][0]) == (np.float32(-16.5), np.float32(-8.8))
+    assert a["radius_sq"][0] == np.float32(0.45) * np.float32(0.45)
+    assert np.allclose([a["albedo_r"][1], a["albedo_g"][1], a["albedo_b"][1]], [0.31764707, 0.93333334, 0.86666668], atol=1e-7)
+    assert (a["center_x"][483], a["center_y"][483], a["radius_sq"][483]) == (-5, 3, 4)
+    assert (a["inv_radius"][484:] == 0).all() and (a["mat_type"][484:] == 255).all()
+    assert (a["center_x"][484:] == np.float32(999999999)).all()
+    # SURVEY.md §8c quotes the lower-left corner of the 1280x720 camera
+    assert np.allclose(r1.create_large_scene(1280, 720).camera_array()[3:6], [-8.27781, -1.750378, 10.947312], atol=1e-5)
+
+
+def test_grid_scene_reduces_to_large_and_scales():
+    big = r1.create_grid_scene(1200, 800, 30, 16)
+    ref = r1.create_large_scene(1200, 800)
+    for k, v in ref.arrays().items():
+        assert big.arrays()[k].tobytes() == v.tobytes(), k
+    g = r1.create_grid_scene(1920, 1080, 400, 250)
+    a = g.arrays()
+    assert g.count == 100008 and int((a["inv_radius"] != 0).sum()) == 100004
+    assert abs(a["center_x"][:100000].min() + 16.5) < 1e-3 and a["radius_sq"][0] < 0.002
+    assert set(np.unique(a["mat_type"])) == {0, 1, 2, 255}
+
+
+def test_tile_and_shard_arithmetic():
+    p = r1.make_params(1200, 800, 10)
+    assert binding.tile_count(p) == (950, 950)  # 38 x 25 tiles
+    assert binding.shard_block_bytes(p) == 950 * 32 * 32 * 3
+    p8 = r1.make_params(1200, 800, 10, shard=3, num_shards=8)
+    assert binding.tile_count(p8) == (950, 119)
+    assert binding.shard_block_bytes(p8) == 119 * 32 * 32 * 3
+    bad = r1.make_params(1200, 800, 10, shard=8, num_shards=8)
+    with pytest.raises(r1.R1Error) as e:
+        binding.tile_count(bad)
+    assert e.value.code == binding.R1_EINVAL
+    with pytest.raises(r1.R1Error) as e:
+        binding.tile_count(r1.make_params(60000, 60000, 10))
+    assert e.value.code == binding.R1_ELIMIT
+
+
+def test_tga_and_log_results_formats(tmp_path):
+    os.chdir(tmp_path)
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (5, 7, 3), dtype=np.uint8)
+    keep = img.copy()
+    r1.tga_write_rgb24("out_x.tga", 7, 5, img)
+    assert open("out_x.tga", "rb").read() == r1o.tga_bytes(keep)
+    assert (img == keep[:, :, ::-1]).all()  # caller's buffer left R/B-swapped (common.h:108-114)
+    r1.log_results("hip", "large", [r1.RESULT(0.5, 27_000_000), r1.RESULT(1.5, 27_000_002)])
+    # common.h:70-73 format, parsed by update_readme.py:30-31
+    assert open("out_large.txt").read() == "hip|1.000s|27000001|27.000 mrays/s|"
+
+
+def test_compute_entry_points_fail_loudly_without_gpu():
+    if r1.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(r1.R1Error) as e:
+        r1.Renderer(0)
+    assert e.value.code == binding.R1_ENODEVICE
+    assert "no CPU fallback" in str(e.value) or "hipGetDeviceCount" in str(e.value)
+
+
+def test_product_does_not_touch_the_oracle():
+    """The product path must not include, import, link or load anything under oracle/."""
+    pkg = os.path.join(ROOT, "rays1bench_amd")
+    bad = re.compile(r'#\s*include\s*[<"][^>"]*oracle|import\s+r1o|from\s+oracle|libr1_oracle|oracle/_ref|CDLL\([^)]*oracle')
+    seen = 0
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".cpp", ".hip", ".h")) or fn == "Makefile":
+                seen += 1
+                assert not bad.search(open(os.path.join(dp, fn)).read()), fn
+    assert seen >= 7
