@@ -100,14 +100,15 @@ typedef struct r1_params
     int32_t variant;     /* R1_VARIANT_*; 0 = default kernel                      */
 } r1_params;
 
-#define R1_MAX_BOUNCES_LIMIT 63
+#define R1_MAX_BOUNCES_LIMIT 51
 
 enum
 {
     R1_VARIANT_DEFAULT = 0,   /* fastest validated kernel                                   */
     R1_VARIANT_REFERENCE = 1, /* pass 1 in the reference's exact arithmetic (rayweek1.cpp:190-202),
                                  no prefilter; slower, used to cross-check the default       */
-    R1_VARIANT_PREFILTER = 2  /* conservative 8-op prefilter + exact re-test */
+    R1_VARIANT_PREFILTER = 2, /* conservative 8-op prefilter + exact re-test */
+    R1_VARIANT_STATS = 3      /* PREFILTER plus in-kernel phase/utilisation counters (diagnostic; r1_last_stats) */
 };
 
 typedef struct r1_context r1_context; /* opaque: device, stream, events, workspace */
@@ -185,6 +186,12 @@ int r1_last_timing(r1_context *ctx, double *trace_kernel_ms, double *total_ms);
  * Frames beyond max_frames reuse the last slot. */
 int r1_timing_begin(r1_context *ctx, int32_t max_frames);
 int r1_timing_end(r1_context *ctx, double *trace_ms_sum, double *total_ms_sum, int32_t *frames);
+
+/* Diagnostic counters of the last R1_VARIANT_STATS render through the context's own stream:
+ * 16 uint64: [0] wave iterations, [1] alive lanes summed over iterations, [2] candidate-loop
+ * trips, [3] lanes that overflowed the candidate list, [4..7] cycles in refill / pass 1 /
+ * candidate re-test / shade, [8] wave cycles, [9] candidates. */
+int r1_last_stats(r1_context *ctx, uint64_t *out16);
 
 /* Launch geometry and occupancy facts of the last render (for reports). */
 typedef struct r1_launch_info

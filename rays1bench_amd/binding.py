@@ -15,7 +15,7 @@ LIBDIR = os.path.join(HERE, "lib")
 
 R1_OK, R1_EINVAL, R1_ENODEVICE, R1_EHIP, R1_ENOMEM, R1_ELIMIT = 0, -1, -2, -3, -4, -5
 SCENE_SMALL, SCENE_MEDIUM, SCENE_LARGE, SCENE_GRID = 0, 1, 2, 3
-VARIANT_DEFAULT, VARIANT_REFERENCE, VARIANT_PREFILTER = 0, 1, 2
+VARIANT_DEFAULT, VARIANT_REFERENCE, VARIANT_PREFILTER, VARIANT_STATS = 0, 1, 2, 3
 
 
 class R1Error(RuntimeError):
@@ -86,6 +86,7 @@ SYMBOLS = [
     ("r1_last_timing", C.c_int, [_ctx, _dblp, _dblp]),
     ("r1_timing_begin", C.c_int, [_ctx, C.c_int32]),
     ("r1_timing_end", C.c_int, [_ctx, _dblp, _dblp, _i32p]),
+    ("r1_last_stats", C.c_int, [_ctx, _u64p]),
     ("r1_last_launch_info", C.c_int, [_ctx, C.POINTER(LaunchInfo)]),
     ("r1_host_scene_create", C.c_int, [C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     ("r1_host_scene_destroy", None, [C.c_void_p]),
@@ -235,6 +236,13 @@ class Renderer:
         a, b, n = C.c_double(), C.c_double(), C.c_int32()
         _check(lib().r1_timing_end(self._c, C.byref(a), C.byref(b), C.byref(n)))
         return float(a.value), float(b.value), int(n.value)
+
+    def last_stats(self):
+        out = (C.c_uint64 * 16)()
+        _check(lib().r1_last_stats(self._c, out))
+        names = ["wave_iterations", "alive_lanes", "candidate_loop_trips", "overflow_lanes", "cycles_refill", "cycles_pass1",
+                 "cycles_candidates", "cycles_shade", "cycles_wave", "candidates"]
+        return {n: int(out[i]) for i, n in enumerate(names)}
 
     def launch_info(self):
         li = LaunchInfo()

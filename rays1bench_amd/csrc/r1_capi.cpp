@@ -85,7 +85,7 @@ struct r1_context
     bool tile_key_valid = false;
     uint32_t n_local_tiles = 0, total_samples = 0;
 
-    int occupancy[3] = {0, 0, 0}; // blocks per CU of the trace kernel, by variant
+    int occupancy[4] = {0, 0, 0, 0}; // blocks per CU of the trace kernel, by variant
 
     r1_launch_info info;
 };
@@ -234,10 +234,15 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
         r1_set_error("r1_set_scene: %u hittable spheres; this build supports up to %d", na, R1_MAX_ACTIVE_10BIT);
         return R1_ELIMIT;
     }
-    const uint32_t ns = (na + 7u) & ~7u;
+    const uint32_t ns = (na + 15u) & ~15u; // the sweep evaluates two 8-sphere chunks per loop trip
 
-    std::vector<float> sweep(4 * (size_t)(ns ? ns : 8)), exact(4 * (size_t)(na ? na : 1)), shade(4 * (size_t)(na ? na : 1)),
+    // sweep table: pair layout + one chunk of prefetch padding (see r1_device.h)
+    const uint32_t ns_alloc = ns + 8;
+    std::vector<float> sweep(4 * (size_t)ns_alloc), exact(4 * (size_t)(na ? na : 1)), shade(4 * (size_t)(na ? na : 1)),
         mat(2 * (size_t)(na ? na : 1));
+    auto sweep_slot = [&](uint32_t a, int comp) -> float & { return sweep[8 * (size_t)(a >> 1) + 2 * comp + (a & 1)]; };
+    for (uint32_t a = 0; a < ns_alloc; ++a) // never-candidate default
+        sweep_slot(a, 0) = sweep_slot(a, 1) = sweep_slot(a, 2) = 0, sweep_slot(a, 3) = INFINITY;
     for (uint32_t a = 0; a < na; ++a)
     {
         const uint32_t i = c->active_to_scene[a];
@@ -245,7 +250,7 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
         const double c2 = (double)cx * cx + (double)cy * cy + (double)cz * cz;
         // Kp = (|c|^2 - r^2) - 2^-17 (|c|^2 + r^2), rounded down: see sweep_prefilter
         const double kp = (c2 - (double)rsq) - ldexp(c2 + (double)rsq, -17) - 1e-30;
-        sweep[4 * a + 0] = cx, sweep[4 * a + 1] = cy, sweep[4 * a + 2] = cz, sweep[4 * a + 3] = round_down(kp);
+        sweep_slot(a, 0) = cx, sweep_slot(a, 1) = cy, sweep_slot(a, 2) = cz, sweep_slot(a, 3) = round_down(kp);
         exact[4 * a + 0] = cx, exact[4 * a + 1] = cy, exact[4 * a + 2] = cz, exact[4 * a + 3] = rsq;
         shade[4 * a + 0] = s->inv_radius[i], shade[4 * a + 1] = s->albedo_r[i], shade[4 * a + 2] = s->albedo_g[i],
                       shade[4 * a + 3] = s->albedo_b[i];
@@ -253,8 +258,6 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
         memcpy(&mat[2 * a], &type, 4);
         mat[2 * a + 1] = s->mat_param[i];
     }
-    for (uint32_t a = na; a < (ns ? ns : 8); ++a) // never-candidate padding
-        sweep[4 * a + 0] = sweep[4 * a + 1] = sweep[4 * a + 2] = 0, sweep[4 * a + 3] = INFINITY;
 
     int rc;
     if ((rc = ensure(c->sweep, sweep.size() * 4)) || (rc = ensure(c->exact, exact.size() * 4)) ||
@@ -329,11 +332,11 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     int rc = r1_params_check(p);
     if (rc)
         return rc;
-    const int variant = p->variant == R1_VARIANT_REFERENCE ? 1 : 2;
+    const int variant = p->variant == R1_VARIANT_REFERENCE ? 1 : (p->variant == R1_VARIANT_STATS ? 3 : 2);
     R1_HIP(hipSetDevice(c->device));
     if ((rc = prepare_tiles(c, p, st)))
         return rc;
-    if ((rc = ensure(c->counters, 64)))
+    if ((rc = ensure(c->counters, 512)))
         return rc;
     if ((rc = ensure(c->samples, (size_t)(c->total_samples ? c->total_samples : 1) * 16)))
         return rc;
@@ -360,6 +363,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     a.queue = (uint32_t *)c->counters.p;
     a.samples = (float4 *)c->samples.p;
     a.num_rays = (unsigned long long *)d_rays;
+    a.stats = variant == 3 ? (unsigned long long *)((char *)c->counters.p + 128) : nullptr;
 
     if (c->occupancy[variant] == 0)
         R1_HIP(r1_trace_occupancy(variant, &c->occupancy[variant]));
@@ -384,6 +388,8 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
             ++c->ring_used;
     }
     R1_HIP(hipMemsetAsync(c->counters.p, 0, 64, st));
+    if (variant == 3)
+        R1_HIP(hipMemsetAsync((char *)c->counters.p + 128, 0, 128, st));
     R1_HIP(hipMemsetAsync(d_rays, 0, 8, st));
     R1_HIP(hipEventRecord(e0, st));
     if (c->total_samples)
@@ -438,7 +444,7 @@ static int render_host(r1_context *c, const r1_params *p, uint8_t *rgb_out, uint
     const size_t out_bytes = sharded ? r1_shard_block_bytes(p) : img_bytes;
     if ((rc = ensure(c->image, out_bytes + 64)))
         return rc;
-    if ((rc = ensure(c->counters, 64)))
+    if ((rc = ensure(c->counters, 512)))
         return rc;
     void *d_rays = (char *)c->counters.p + 32;
     if ((rc = enqueue_frame(c, p, c->image.p, sharded ? 1 : 0, d_rays, c->stream)))
@@ -567,6 +573,16 @@ extern "C" int r1_last_timing(r1_context *c, double *trace_kernel_ms, double *to
         *trace_kernel_ms = a;
     if (total_ms)
         *total_ms = b;
+    return R1_OK;
+}
+
+extern "C" int r1_last_stats(r1_context *c, uint64_t *out16)
+{
+    if (!c || !out16 || !c->counters.p)
+        return R1_EINVAL;
+    R1_HIP(hipSetDevice(c->device));
+    R1_HIP(hipStreamSynchronize(c->stream));
+    R1_HIP(hipMemcpy(out16, (char *)c->counters.p + 128, 128, hipMemcpyDeviceToHost));
     return R1_OK;
 }
 

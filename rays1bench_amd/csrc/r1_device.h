@@ -6,16 +6,18 @@
 
 // Launch geometry of the trace kernel.
 #define R1_BLOCK 256        // threads per workgroup = 4 wave64
-#define R1_CAND_CAP 8       // per-lane candidate slots in LDS before an early flush
-#define R1_STACK_WORDS 21   // ceil(63 / 3) packed 10-bit hit indices per lane
+#define R1_CAND_CAP 16      // per-lane candidate slots in LDS (flushed when a lane passes CAP-8)
+#define R1_PAIR_CAP 1024    // (lane, sphere) pairs of one wave: 64 lanes x R1_CAND_CAP
+#define R1_STACK_WORDS 17   // ceil(51 / 3) packed 10-bit hit indices per lane (max_bounces <= 51)
 #define R1_CHUNK 256        // samples a wave takes from the global queue per atomic
 #define R1_MAX_ACTIVE_10BIT 1023
 
 // Everything the trace kernel needs; passed by value (kernarg segment => SGPRs).
 struct R1DeviceScene
 {
-    // Prefilter table, one float4 per ACTIVE sphere (inv_radius != 0), padded with
-    // never-candidate entries to a multiple of 8: {cx, cy, cz, Kp}, Kp = |c|^2 - r^2 - slack.
+    // Prefilter table over the ACTIVE spheres (inv_radius != 0), 8 floats per PAIR of spheres
+    // {cx0 cx1 cy0 cy1 cz0 cz1 Kp0 Kp1}, Kp = |c|^2 - r^2 - slack; padded with never-candidate
+    // entries (Kp = +inf) to a multiple of 16 spheres PLUS one extra chunk of 8 (prefetch target).
     const float4 *sweep;
     // Exact table, same indexing: {cx, cy, cz, radius_sq} and {inv_radius, albedo rgb},
     // {type, param}.
@@ -23,7 +25,7 @@ struct R1DeviceScene
     const float4 *shade;   // {inv_radius, albedo_r, albedo_g, albedo_b}
     const float2 *mat;     // {bit_cast<float>(type), param}
     uint32_t n_active;     // real entries
-    uint32_t n_sweep;      // padded to a multiple of 8
+    uint32_t n_sweep;      // padded to a multiple of 16 (the table holds 8 more for the prefetch)
 };
 
 struct R1DeviceCamera
@@ -47,6 +49,7 @@ struct R1TraceArgs
     uint32_t *queue;             // global sample counter (zeroed before the launch)
     float4 *samples;             // [total_samples] {r, g, b, bit_cast<float>(rays)}
     unsigned long long *num_rays; // accumulated color() invocations
+    unsigned long long *stats;    // diagnostic counters (R1_VARIANT_STATS builds only), else null
 };
 
 struct R1ResolveArgs

@@ -49,6 +49,15 @@ struct V3
 // index turns into scalar loads (SMEM) instead of vector loads
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef const f4 __attribute__((address_space(4))) *cf4_ptr;
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float f16 __attribute__((ext_vector_type(16)));
+typedef const f16 __attribute__((address_space(4))) *cf16_ptr;
+
+// Correctly rounded sqrt / division.  NOT __fsqrt_rn/__fdiv_rn: without
+// OCML_BASIC_ROUNDED_OPERATIONS hipcc maps __fsqrt_rn to the approximate v_sqrt_f32.  Plain
+// sqrtf() and `/` are IEEE under -fhip-fp32-correctly-rounded-divide-sqrt (set in the Makefile).
+__device__ __forceinline__ float ieee_sqrt(float x) { return __builtin_sqrtf(x); }
+__device__ __forceinline__ float ieee_div(float a, float b) { return a / b; }
 
 __device__ __forceinline__ V3 mk(float x, float y, float z)
 {
@@ -63,7 +72,7 @@ __device__ __forceinline__ V3 vneg(V3 a) { return mk(-a.x, -a.y, -a.z); }
 // mymath.h:205-207: sum(a*b) = (x + y) + z
 __device__ __forceinline__ float vdot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 // mymath.h:211: v * (1.0f / length(v)); Ray::Ray normalises every direction (rayweek1.cpp:107)
-__device__ __forceinline__ V3 vunit(V3 v) { return vscale(v, __fdiv_rn(1.0f, __fsqrt_rn(vdot(v, v)))); }
+__device__ __forceinline__ V3 vunit(V3 v) { return vscale(v, ieee_div(1.0f, ieee_sqrt(vdot(v, v)))); }
 __device__ __forceinline__ V3 ld3(const float *p) { return mk(p[0], p[1], p[2]); }
 
 // mymath.h:17-25
@@ -124,7 +133,7 @@ __device__ __forceinline__ void exact_test(const f4 e, uint32_t idx, const V3 o,
     const float discr = nb * nb - c;
     if (!(__float_as_uint(discr) >> 31))
     {
-        const float discr_sq = __fsqrt_rn(discr);
+        const float discr_sq = ieee_sqrt(discr);
         float temp = nb - discr_sq;
         if (temp < t_max && temp > 0.001f)
         {
@@ -160,57 +169,173 @@ __device__ __forceinline__ void sweep_reference(const R1DeviceScene &S, const V3
 // The slack 2^-17 (|c|^2 + r^2 + |o|^2) exceeds the worst-case fp32 error of BOTH this form and
 // the reference's form, so every sphere whose reference discriminant has a
 // clear sign bit is flagged here; exact_test then applies the reference's own rule.
-__device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const V3 o, const V3 d, float &t_max, int &hit_index,
-                                                uint16_t *cand /* [R1_CAND_CAP][R1_BLOCK] */, const int tid)
+// What ONE candidate sphere offers a ray, independent of the other candidates: pass 2 of
+// Hitable::hit (rayweek1.cpp:294-313) accepts t1 = nb - s when t1 > t_min, otherwise
+// t2 = nb + s when t2 > t_min, each only if it is below the running t_max; since t2 >= t1 a
+// sphere whose t1 fails `< t_max` cannot pass with t2, so the sphere's offer is fixed and the
+// loop result is the minimum offer, ties to the lowest index (strict `<` keeps the earlier one).
+// Returns FLT_MAX for "no offer".
+__device__ __forceinline__ float exact_offer(const f4 e, const V3 o, const V3 d)
 {
+    const float cox = e.x - o.x;
+    const float coy = e.y - o.y;
+    const float coz = e.z - o.z;
+    const float nb = __fmaf_rn(coz, d.z, __fmaf_rn(coy, d.y, cox * d.x));
+    const float c = __fmaf_rn(coz, coz, __fmaf_rn(coy, coy, cox * cox)) - e.w;
+    const float discr = nb * nb - c;
+    float offer = FLT_MAX;
+    if (!(__float_as_uint(discr) >> 31))
+    {
+        const float discr_sq = ieee_sqrt(discr);
+        const float t1 = nb - discr_sq;
+        const float t = (t1 > 0.001f) ? t1 : nb + discr_sq;
+        if (t > 0.001f && t < FLT_MAX)
+            offer = t;
+    }
+    return offer;
+}
+
+// Wave-cooperative exact phase.  Per-lane candidate counts are very uneven (mean 2.2, max of
+// 64 lanes ~8.5, a few rays skim a whole row of spheres), so the (ray, sphere) pairs of the
+// whole wave are compacted into one dense LDS list and re-tested 64 at a time by whichever
+// lane comes next: ~3 full-width trips instead of ~9 mostly-empty ones.  Offers are combined
+// per ray with a 64-bit LDS atomic min on {t bits, sphere index}: closest hit, ties to the
+// lowest index — the reference's rule.  Must be called by ALL 64 lanes (full EXEC).
+template <bool STATS>
+__device__ __forceinline__ void cooperative_exact(const R1DeviceScene &S, const V3 o, const V3 d, int cnt, const uint16_t *cand,
+                                                  uint16_t *pairs /* this wave's [R1_PAIR_CAP] */, unsigned long long *best /* this wave's [64] */,
+                                                  const int tid, const int lane, unsigned long long *wstat)
+{
+    // exclusive prefix sum of cnt over the wave
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1)
+    {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off)
+            incl += v;
+    }
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    const int excl = incl - cnt;
+    for (int j = 0; j < cnt; ++j)
+        pairs[excl + j] = (uint16_t)(((uint32_t)lane << 10) | cand[j * R1_BLOCK + tid]);
+    __builtin_amdgcn_wave_barrier();
+    if (STATS)
+        wstat[2] += (unsigned long long)((total + 63) >> 6);
+    for (int base = 0; base < total; base += 64) // wave-uniform trip count
+    {
+        const int j = base + lane;
+        const bool have = j < total;
+        const uint32_t pr = have ? (uint32_t)pairs[j] : ((uint32_t)lane << 10);
+        const int owner = (int)(pr >> 10);
+        const uint32_t idx = pr & 1023u;
+        V3 ro, rd;
+        ro.x = __shfl(o.x, owner, 64), ro.y = __shfl(o.y, owner, 64), ro.z = __shfl(o.z, owner, 64);
+        rd.x = __shfl(d.x, owner, 64), rd.y = __shfl(d.y, owner, 64), rd.z = __shfl(d.z, owner, 64);
+        if (have)
+        {
+            const float t = exact_offer(((const f4 *)S.exact)[idx], ro, rd);
+            if (t < FLT_MAX)
+                atomicMin(&best[owner], ((unsigned long long)__float_as_uint(t) << 32) | idx);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- sweep, prefilter form -----------------------------------------------------------------
+// (formula and slack: see the comment block above)  Called by all 64 lanes; lanes with
+// alive == false never flag a candidate but help in the cooperative exact phase.
+template <bool STATS>
+__device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const bool alive, const V3 o, const V3 d, float &t_max,
+                                                int &hit_index, uint16_t *cand /* [R1_CAND_CAP][R1_BLOCK] */,
+                                                uint16_t *pairs /* [R1_BLOCK/64][R1_PAIR_CAP] */,
+                                                unsigned long long *best /* [R1_BLOCK] */, const int tid, unsigned long long *wstat)
+{
+    const int lane = tid & 63;
+    uint16_t *wpairs = pairs + (tid >> 6) * R1_PAIR_CAP;
+    unsigned long long *wbest = best + (tid & ~63);
+    const unsigned long long NONE = ~0ull;
+
     const float negod = -__fmaf_rn(o.z, d.z, __fmaf_rn(o.y, d.y, o.x * d.x));
     const float oo = __fmaf_rn(o.z, o.z, __fmaf_rn(o.y, o.y, o.x * o.x));
-    const float oo_adj = __fmaf_rn(oo, -0x1p-17f, oo);
+    // dead lanes: t' = +inf => q = -inf (or NaN) => never >= Kp
+    const float oo_adj = alive ? __fmaf_rn(oo, -0x1p-17f, oo) : __builtin_inff();
     const float mx = -2.0f * o.x, my = -2.0f * o.y, mz = -2.0f * o.z;
 
+    wbest[lane] = NONE;
     int cnt = 0;
-    // constant address space + wave-uniform index => s_load_dwordx4..x16 into SGPRs
-    const cf4_ptr tab = (cf4_ptr)S.sweep;
-    for (uint32_t i = 0; i < S.n_sweep; i += 8)
-    {
-        bool c[8];
-        unsigned long long any = 0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-        {
-            const f4 s = tab[i + u];
-            const float nb = __fmaf_rn(s.z, d.z, __fmaf_rn(s.y, d.y, __fmaf_rn(s.x, d.x, negod)));
-            const float t = __fmaf_rn(s.z, mz, __fmaf_rn(s.y, my, __fmaf_rn(s.x, mx, oo_adj)));
-            const float q = __fmaf_rn(nb, nb, -t);
-            c[u] = q >= s.w;
-            any |= __ballot(c[u]);
-        }
-        if (any) // wave-uniform: scalar branch
-        {
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (c[u])
-                {
-                    if (cnt < R1_CAND_CAP)
-                        cand[cnt * R1_BLOCK + tid] = (uint16_t)(i + u);
-                    ++cnt;
-                }
-        }
+
+    // Pair layout (r1_capi.cpp): 8 floats per two spheres {cx0 cx1 cy0 cy1 cz0 cz1 Kp0 Kp1}, so
+    // that every v_pk_fma_f32 takes an aligned SGPR pair straight from the scalar load: two
+    // spheres per VALU instruction, 3.5 + 1 instructions per sphere.  A chunk = 8 spheres =
+    // two s_load_dwordx16; the NEXT chunk is requested before the current one is evaluated
+    // (the table carries one never-candidate chunk of padding behind the last real one).
+    const v2f dxx = {d.x, d.x}, dyy = {d.y, d.y}, dzz = {d.z, d.z};
+    const v2f mxx = {mx, mx}, myy = {my, my}, mzz = {mz, mz};
+    const v2f nod = {negod, negod}, ooa = {oo_adj, oo_adj};
+    const cf16_ptr tab = (cf16_ptr)S.sweep;
+    const uint32_t chunks = S.n_sweep >> 3; // even (r1_capi.cpp pads to 16 spheres + one prefetch chunk)
+
+#define R1_PAIR(P, L, B)                                                                                               \
+    {                                                                                                                  \
+        const v2f cx = {L[B + 0], L[B + 1]}, cy = {L[B + 2], L[B + 3]}, cz = {L[B + 4], L[B + 5]};                     \
+        const v2f nb = __builtin_elementwise_fma(cz, dzz, __builtin_elementwise_fma(cy, dyy, __builtin_elementwise_fma(cx, dxx, nod))); \
+        const v2f t = __builtin_elementwise_fma(cz, mzz, __builtin_elementwise_fma(cy, myy, __builtin_elementwise_fma(cx, mxx, ooa))); \
+        const v2f q = __builtin_elementwise_fma(nb, nb, -t);                                                           \
+        c[2 * P] = q.x >= L[B + 6];                                                                                    \
+        c[2 * P + 1] = q.y >= L[B + 7];                                                                                \
+        any |= __ballot(c[2 * P]) | __ballot(c[2 * P + 1]);                                                            \
     }
-    if (cnt <= R1_CAND_CAP)
-    {
-        for (int j = 0; j < cnt; ++j)
-        {
-            const uint32_t idx = cand[j * R1_BLOCK + tid];
-            exact_test(((const f4 *)S.exact)[idx], idx, o, d, t_max, hit_index);
-        }
+#define R1_CHUNK_EVAL(L0, L1, CH)                                                                                      \
+    {                                                                                                                  \
+        bool c[8];                                                                                                     \
+        unsigned long long any = 0;                                                                                    \
+        R1_PAIR(0, L0, 0) R1_PAIR(1, L0, 8) R1_PAIR(2, L1, 0) R1_PAIR(3, L1, 8)                                        \
+        if (any) /* wave-uniform: scalar branch */                                                                     \
+        {                                                                                                              \
+            /* a chunk adds at most 8 entries per lane: make room first, then append unchecked */                      \
+            if (__ballot(cnt > R1_CAND_CAP - 8))                                                                       \
+            {                                                                                                          \
+                cooperative_exact<STATS>(S, o, d, cnt, cand, wpairs, wbest, tid, lane, wstat);                         \
+                cnt = 0;                                                                                               \
+            }                                                                                                          \
+            _Pragma("unroll") for (int u = 0; u < 8; ++u) if (c[u])                                                    \
+            {                                                                                                          \
+                cand[cnt * R1_BLOCK + tid] = (uint16_t)(8 * (CH) + u);                                                 \
+                ++cnt;                                                                                                 \
+            }                                                                                                          \
+        }                                                                                                              \
     }
-    else
+    // two register sets (A, B) alternate: while one chunk is evaluated the next one loads
+    f16 a0 = tab[0], a1 = tab[1];
+    for (uint32_t ch = 0; ch < chunks; ch += 2)
     {
-        // more candidates than LDS slots (a ray skimming a row of spheres): exact sweep
-        const cf4_ptr tabx = (cf4_ptr)S.exact;
-        for (uint32_t i = 0; i < S.n_active; ++i)
-            exact_test(tabx[i], i, o, d, t_max, hit_index);
+        // Scalar loads return out of order, so lgkmcnt can only be waited to 0: make set A land
+        // BEFORE set B is requested (the empty asm "uses" A, which places the wait here), then
+        // evaluate A with B in flight and no further wait.
+        asm volatile("" ::"s"(a0[0]), "s"(a1[0]));
+        const f16 b0 = tab[2 * ch + 2], b1 = tab[2 * ch + 3];
+        __builtin_amdgcn_sched_barrier(0);
+        R1_CHUNK_EVAL(a0, a1, ch)
+        asm volatile("" ::"s"(b0[0]), "s"(b1[0]));
+        a0 = tab[2 * ch + 4], a1 = tab[2 * ch + 5];
+        __builtin_amdgcn_sched_barrier(0);
+        R1_CHUNK_EVAL(b0, b1, ch + 1)
+    }
+#undef R1_CHUNK_EVAL
+#undef R1_PAIR
+    if (STATS)
+    {
+        wstat[5] += __builtin_readcyclecounter() - wstat[15];
+        wstat[15] = __builtin_readcyclecounter();
+        wstat[9] += (unsigned long long)cnt; // per-lane (summed over lanes at the end)
+    }
+    cooperative_exact<STATS>(S, o, d, cnt, cand, wpairs, wbest, tid, lane, wstat);
+    const unsigned long long key = wbest[lane];
+    if (key != NONE)
+    {
+        t_max = __uint_as_float((uint32_t)(key >> 32));
+        hit_index = (int)(uint32_t)(key & 0xFFFFFFFFull);
     }
 }
 
@@ -293,11 +418,22 @@ __device__ __forceinline__ void start_sample(const R1TraceArgs &A, Path &p, uint
 // The trace kernel.  Persistent: grid = CUs x blocks/CU, every wave loops until the global
 // sample queue is empty and its own lanes have finished their paths.
 // ============================================================================================
-template <int VARIANT>
+// STATS = diagnostic build (variant R1_VARIANT_STATS): same results, plus per-phase cycle and
+// utilisation counters in A.stats; never used by the product path.
+template <int VARIANT, bool STATS>
 __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
 {
+    unsigned long long wstat[16];
+    if (STATS)
+    {
+        for (int i = 0; i < 16; ++i)
+            wstat[i] = 0;
+        wstat[14] = __builtin_readcyclecounter();
+    }
     __shared__ uint32_t s_stack[R1_STACK_WORDS * R1_BLOCK];
     __shared__ uint16_t s_cand[R1_CAND_CAP * R1_BLOCK];
+    __shared__ uint16_t s_pairs[(R1_BLOCK / 64) * R1_PAIR_CAP];
+    __shared__ unsigned long long s_best[R1_BLOCK];
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
@@ -316,6 +452,8 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
     for (;;)
     {
         // ---- refill finished lanes from the wave's chunk of the global sample queue ----
+        if (STATS)
+            wstat[15] = __builtin_readcyclecounter();
         unsigned long long need = __ballot(!alive);
         while (need)
         {
@@ -347,18 +485,33 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
         }
         if (__ballot(alive) == 0ull)
             break;
+        if (STATS)
+        {
+            wstat[4] += __builtin_readcyclecounter() - wstat[15];
+            wstat[15] = __builtin_readcyclecounter();
+            wstat[0] += 1;
+            wstat[1] += (unsigned long long)__popcll(__ballot(alive));
+        }
+
+        // ---- one color() level: hit test for every live lane (rayweek1.cpp:519) ----
+        float t_hit = FLT_MAX;
+        int hit = -1;
+        if (VARIANT == 1)
+        {
+            if (alive)
+                sweep_reference(A.scene, p.o, p.d, t_hit, hit);
+        }
+        else
+            sweep_prefilter<STATS>(A.scene, alive, p.o, p.d, t_hit, hit, s_cand, s_pairs, s_best, tid, wstat);
+        if (STATS)
+        {
+            wstat[6] += __builtin_readcyclecounter() - wstat[15];
+            wstat[15] = __builtin_readcyclecounter();
+        }
 
         if (alive)
         {
-            // ---- one color() level: count, hit test (rayweek1.cpp:517-519) ----
-            ++p.rays;
-            float t_hit = FLT_MAX;
-            int hit = -1;
-            if (VARIANT == 1)
-                sweep_reference(A.scene, p.o, p.d, t_hit, hit);
-            else
-                sweep_prefilter(A.scene, p.o, p.d, t_hit, hit, s_cand, tid);
-
+            ++p.rays; // rayweek1.cpp:517
             bool done = false;
             V3 col = mk(0, 0, 0);
             if (hit >= 0)
@@ -413,7 +566,7 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
                         else
                         {
                             outward = n;
-                            ni_over_nt = __fdiv_rn(1.0f, ref_idx);
+                            ni_over_nt = ieee_div(1.0f, ref_idx);
                             cosine = -ddn;
                         }
                         // refract rayweek1.cpp:439-452
@@ -423,9 +576,9 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
                         V3 refracted = mk(0, 0, 0);
                         if (discriminant > 0)
                         {
-                            refracted = vsub(vscale(vsub(p.d, vscale(outward, dt)), ni_over_nt), vscale(outward, __fsqrt_rn(discriminant)));
+                            refracted = vsub(vscale(vsub(p.d, vscale(outward, dt)), ni_over_nt), vscale(outward, ieee_sqrt(discriminant)));
                             // schlick rayweek1.cpp:454-459
-                            float r0 = __fdiv_rn(1.0f - ref_idx, 1.0f + ref_idx);
+                            float r0 = ieee_div(1.0f - ref_idx, 1.0f + ref_idx);
                             r0 = r0 * r0;
                             reflect_prob = r0 + (1.0f - r0) * pow5(1.0f - cosine);
                         }
@@ -459,6 +612,22 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
                 alive = false;
             }
         }
+        if (STATS)
+            wstat[7] += __builtin_readcyclecounter() - wstat[15];
+    }
+    if (STATS)
+    {
+        // [0] wave iterations [1] alive lanes [2] candidate-loop trips [3] overflow lanes
+        // [4] refill cycles [5] pass-1 cycles [6] candidate cycles [7] shade cycles [8] wave cycles
+        // [9] candidates (all lanes)
+        wstat[8] = __builtin_readcyclecounter() - wstat[14];
+        unsigned long long c9 = wstat[9];
+        for (int off = 32; off > 0; off >>= 1)
+            c9 += __shfl_down(c9, off, 64);
+        wstat[9] = c9;
+        if (lane == 0 && A.stats)
+            for (int i = 0; i < 10; ++i)
+                atomicAdd(&A.stats[i], wstat[i]);
     }
 
     // ray count: wave reduction, one atomic per wave (rayweek1.cpp:809-813)
@@ -468,8 +637,6 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
         atomicAdd(A.num_rays, lane_rays);
 }
 
-template __global__ void r1_trace_kernel<1>(const R1TraceArgs);
-template __global__ void r1_trace_kernel<2>(const R1TraceArgs);
 
 // ============================================================================================
 // Resolve: one thread per pixel of this shard; sums the spp samples in sample order and
@@ -496,7 +663,7 @@ __global__ void __launch_bounds__(256) r1_resolve_kernel(const R1ResolveArgs A)
                 cr += v.x, cg += v.y, cb += v.z; // col += color(...) rayweek1.cpp:762
             }
             cr *= A.inv_spp, cg *= A.inv_spp, cb *= A.inv_spp;
-            cr = __fsqrt_rn(cr), cg = __fsqrt_rn(cg), cb = __fsqrt_rn(cb);
+            cr = ieee_sqrt(cr), cg = ieee_sqrt(cg), cb = ieee_sqrt(cb);
             const uint8_t r = (uint8_t)(int)(cr * 255.99f);
             const uint8_t g = (uint8_t)(int)(cg * 255.99f);
             const uint8_t b = (uint8_t)(int)(cb * 255.99f);
@@ -538,9 +705,11 @@ __global__ void __launch_bounds__(256)
 extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int blocks, hipStream_t stream)
 {
     if (variant == 1)
-        hipLaunchKernelGGL(r1_trace_kernel<1>, dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
+        hipLaunchKernelGGL((r1_trace_kernel<1, false>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
+    else if (variant == 3)
+        hipLaunchKernelGGL((r1_trace_kernel<2, true>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
     else
-        hipLaunchKernelGGL(r1_trace_kernel<2>, dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
+        hipLaunchKernelGGL((r1_trace_kernel<2, false>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
     return hipGetLastError();
 }
 
@@ -568,6 +737,8 @@ extern "C" hipError_t r1_launch_assemble(const void *blocks, void *rgb, int widt
 extern "C" hipError_t r1_trace_occupancy(int variant, int *blocks_per_cu)
 {
     if (variant == 1)
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<1>, R1_BLOCK, 0);
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<2>, R1_BLOCK, 0);
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<1, false>, R1_BLOCK, 0);
+    if (variant == 3)
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<2, true>, R1_BLOCK, 0);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<2, false>, R1_BLOCK, 0);
 }

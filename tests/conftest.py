@@ -3,6 +3,14 @@ import sys
 
 import pytest
 
+# torch bundles its own HIP runtime (torch/lib/libamdhip64.so).  When a test hands torch
+# device pointers to librays1.so both must share ONE runtime: importing torch first makes
+# librays1's DT_NEEDED libamdhip64.so resolve to the copy torch already loaded.
+try:
+    import torch  # noqa: F401
+except Exception:  # torch is plumbing for the device-pointer tests only
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
