@@ -91,7 +91,7 @@ def main():
 
     import torch
     import rays1bench_amd as r1
-    from rays1bench_amd import binding
+    from rays1bench_amd import binding, sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -126,8 +126,7 @@ def main():
     def step():
         rend.render_shard_device(p, block.data_ptr(), rays.data_ptr(), stream)
         if n > 1:
-            dist.all_gather_into_tensor(gathered, block)
-            dist.all_reduce(rays)
+            sharding.gather_blocks(dist, block, gathered, rays)
         rend.assemble_device(p, gathered.data_ptr(), image.data_ptr(), stream)
 
     def fence():

@@ -79,11 +79,10 @@ struct r1_context
     bool have_scene = false;
 
     // per-frame workspace
-    DevBuf tile_base, counters, samples, image;
-    std::vector<uint32_t> h_tile_base;
+    DevBuf counters, samples, image;
     r1_params tile_key;
     bool tile_key_valid = false;
-    uint32_t n_local_tiles = 0, total_samples = 0;
+    uint32_t n_local_tiles = 0, total_samples = 0, full = 0;
 
     int occupancy[4] = {0, 0, 0, 0}; // blocks per CU of the trace kernel, by variant
 
@@ -180,7 +179,7 @@ extern "C" void r1_destroy(r1_context *c)
     if (c->stream)
         (void)hipStreamSynchronize(c->stream);
     release(c->sweep), release(c->exact), release(c->shade), release(c->mat);
-    release(c->tile_base), release(c->counters), release(c->samples), release(c->image);
+    release(c->counters), release(c->samples), release(c->image);
     for (hipEvent_t e : c->ring)
         (void)hipEventDestroy(e);
     if (c->ev0)
@@ -239,7 +238,7 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
     // sweep table: pair layout + one chunk of prefetch padding (see r1_device.h)
     const uint32_t ns_alloc = ns + 8;
     std::vector<float> sweep(4 * (size_t)ns_alloc), exact(4 * (size_t)(na ? na : 1)), shade(4 * (size_t)(na ? na : 1)),
-        mat(2 * (size_t)(na ? na : 1));
+        mat(4 * (size_t)(na ? na : 1));
     auto sweep_slot = [&](uint32_t a, int comp) -> float & { return sweep[8 * (size_t)(a >> 1) + 2 * comp + (a & 1)]; };
     for (uint32_t a = 0; a < ns_alloc; ++a) // never-candidate default
         sweep_slot(a, 0) = sweep_slot(a, 1) = sweep_slot(a, 2) = 0, sweep_slot(a, 3) = INFINITY;
@@ -255,8 +254,15 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
         shade[4 * a + 0] = s->inv_radius[i], shade[4 * a + 1] = s->albedo_r[i], shade[4 * a + 2] = s->albedo_g[i],
                       shade[4 * a + 3] = s->albedo_b[i];
         uint32_t type = s->mat_type[i];
-        memcpy(&mat[2 * a], &type, 4);
-        mat[2 * a + 1] = s->mat_param[i];
+        memcpy(&mat[4 * a], &type, 4);
+        const float ref_idx = s->mat_param[i];
+        mat[4 * a + 1] = ref_idx;
+        // Dielectric constants the reference recomputes per hit with IEEE float ops
+        // (rayweek1.cpp:489 `1.0f / _refIdx`, :456-457 schlick r0): same operations, done once
+        float r0 = (1 - ref_idx) / (1 + ref_idx);
+        r0 = r0 * r0;
+        mat[4 * a + 2] = type == R1_MAT_DIELECTRIC ? 1.0f / ref_idx : 0.0f;
+        mat[4 * a + 3] = type == R1_MAT_DIELECTRIC ? r0 : 0.0f;
     }
 
     int rc;
@@ -291,31 +297,41 @@ static bool same_tiling(const r1_params &a, const r1_params &b)
            a.shard == b.shard && a.num_shards == b.num_shards;
 }
 
-static int prepare_tiles(r1_context *c, const r1_params *p, hipStream_t st)
+static R1FastDiv make_div(uint32_t d)
+{
+    R1FastDiv r;
+    uint32_t sh = 0;
+    while ((2u << sh) <= d && sh < 31)
+        ++sh; // floor(log2 d)
+    if ((d & (d - 1)) == 0)
+    {
+        r.pow2 = 1, r.shift = sh, r.mul = 0;
+    }
+    else
+    {
+        r.pow2 = 0, r.shift = sh;
+        r.mul = (uint32_t)((((uint64_t)1 << (32 + sh)) + d - 1) / d);
+    }
+    return r;
+}
+
+static int prepare_tiles(r1_context *c, const r1_params *p)
 {
     if (c->tile_key_valid && same_tiling(c->tile_key, *p))
         return R1_OK;
     const int tiles_x = (p->width + p->tile_w - 1) / p->tile_w;
     const int tiles_y = (p->height + p->tile_h - 1) / p->tile_h;
     const int total = tiles_x * tiles_y;
-    c->h_tile_base.clear();
-    uint64_t acc = 0;
-    for (int t = p->shard; t < total; t += p->num_shards)
+    const uint32_t local = total > p->shard ? (uint32_t)((total - p->shard + p->num_shards - 1) / p->num_shards) : 0u;
+    const uint64_t full = (uint64_t)p->tile_w * p->tile_h * p->spp;
+    if (full * local >= ((uint64_t)1 << 31) || (uint64_t)total * p->num_shards >= ((uint64_t)1 << 31))
     {
-        const int x0 = (t % tiles_x) * p->tile_w, y0 = (t / tiles_x) * p->tile_h;
-        const int tw = p->tile_w < p->width - x0 ? p->tile_w : p->width - x0;
-        const int th = p->tile_h < p->height - y0 ? p->tile_h : p->height - y0;
-        c->h_tile_base.push_back((uint32_t)acc);
-        acc += (uint64_t)tw * th * p->spp;
+        r1_set_error("frame %dx%dx%d with %dx%d tiles exceeds 2^31 sample slots per device", p->width, p->height, p->spp, p->tile_w, p->tile_h);
+        return R1_ELIMIT;
     }
-    c->n_local_tiles = (uint32_t)c->h_tile_base.size();
-    c->h_tile_base.push_back((uint32_t)acc);
-    c->total_samples = (uint32_t)acc;
-    int rc = ensure(c->tile_base, c->h_tile_base.size() * 4);
-    if (rc)
-        return rc;
-    R1_HIP(hipStreamSynchronize(st));
-    R1_HIP(hipMemcpy(c->tile_base.p, c->h_tile_base.data(), c->h_tile_base.size() * 4, hipMemcpyHostToDevice));
+    c->n_local_tiles = local;
+    c->full = (uint32_t)full;
+    c->total_samples = (uint32_t)(full * local);
     c->tile_key = *p;
     c->tile_key_valid = true;
     return R1_OK;
@@ -334,7 +350,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
         return rc;
     const int variant = p->variant == R1_VARIANT_REFERENCE ? 1 : (p->variant == R1_VARIANT_STATS ? 3 : 2);
     R1_HIP(hipSetDevice(c->device));
-    if ((rc = prepare_tiles(c, p, st)))
+    if ((rc = prepare_tiles(c, p)))
         return rc;
     if ((rc = ensure(c->counters, 512)))
         return rc;
@@ -346,7 +362,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     a.scene.sweep = (const float4 *)c->sweep.p;
     a.scene.exact = (const float4 *)c->exact.p;
     a.scene.shade = (const float4 *)c->shade.p;
-    a.scene.mat = (const float2 *)c->mat.p;
+    a.scene.mat = (const float4 *)c->mat.p;
     a.scene.n_active = c->n_active;
     a.scene.n_sweep = c->n_sweep;
     a.cam = c->cam;
@@ -358,7 +374,11 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     a.tiles_x = (p->width + p->tile_w - 1) / p->tile_w;
     a.shard = p->shard, a.num_shards = p->num_shards;
     a.n_local_tiles = c->n_local_tiles;
-    a.tile_sample_base = (const uint32_t *)c->tile_base.p;
+    a.full = c->full;
+    a.div_full = make_div(c->full);
+    a.div_spp = make_div((uint32_t)p->spp);
+    a.div_tw = make_div((uint32_t)p->tile_w);
+    a.div_tx = make_div((uint32_t)a.tiles_x);
     a.total_samples = c->total_samples;
     a.queue = (uint32_t *)c->counters.p;
     a.samples = (float4 *)c->samples.p;
@@ -399,7 +419,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     R1ResolveArgs r;
     memset(&r, 0, sizeof(r));
     r.samples = (const float4 *)c->samples.p;
-    r.tile_sample_base = (const uint32_t *)c->tile_base.p;
+    r.full = c->full;
     r.width = p->width, r.height = p->height, r.spp = p->spp;
     r.tile_w = p->tile_w, r.tile_h = p->tile_h, r.tiles_x = a.tiles_x;
     r.shard = p->shard, r.num_shards = p->num_shards;
@@ -485,7 +505,7 @@ static int render_host(r1_context *c, const r1_params *p, uint8_t *rgb_out, uint
     }
     if (samples_out)
     {
-        // device order is tile-major (tile, pixel-in-tile, sample); the ABI order is
+        // device order is [padded tile][sample][pixel in tile]; the ABI order is
         // ((y*width + x)*spp + s)
         std::vector<float> tmp((size_t)c->total_samples * 4);
         R1_HIP(hipMemcpy(tmp.data(), c->samples.p, tmp.size() * 4, hipMemcpyDeviceToHost));
@@ -495,11 +515,13 @@ static int render_host(r1_context *c, const r1_params *p, uint8_t *rgb_out, uint
             const int x0 = ((int)lt % tiles_x) * p->tile_w, y0 = ((int)lt / tiles_x) * p->tile_h;
             const int tw = p->tile_w < p->width - x0 ? p->tile_w : p->width - x0;
             const int th = p->tile_h < p->height - y0 ? p->tile_h : p->height - y0;
-            const float *src = tmp.data() + (size_t)c->h_tile_base[lt] * 4;
+            const float *src = tmp.data() + (size_t)lt * c->full * 4;
+            const size_t tile_px = (size_t)p->tile_w * p->tile_h;
             for (int ly = 0; ly < th; ++ly)
                 for (int lx = 0; lx < tw; ++lx)
-                    memcpy(samples_out + (((size_t)(y0 + ly) * p->width + (x0 + lx)) * p->spp) * 4,
-                           src + ((size_t)(ly * tw + lx) * p->spp) * 4, (size_t)p->spp * 16);
+                    for (int sm = 0; sm < p->spp; ++sm)
+                        memcpy(samples_out + (((size_t)(y0 + ly) * p->width + (x0 + lx)) * p->spp + sm) * 4,
+                               src + ((size_t)sm * tile_px + (size_t)(ly * p->tile_w + lx)) * 4, 16);
         }
     }
     return R1_OK;

@@ -9,8 +9,16 @@
 #define R1_CAND_CAP 16      // per-lane candidate slots in LDS (flushed when a lane passes CAP-8)
 #define R1_PAIR_CAP 1024    // (lane, sphere) pairs of one wave: 64 lanes x R1_CAND_CAP
 #define R1_STACK_WORDS 17   // ceil(51 / 3) packed 10-bit hit indices per lane (max_bounces <= 51)
-#define R1_CHUNK 256        // samples a wave takes from the global queue per atomic
+#define R1_CHUNK 256        // most samples a wave takes from the global queue per atomic
+#define R1_CHUNK_MIN 32      // fewest (end of the queue: guided self-scheduling)
 #define R1_MAX_ACTIVE_10BIT 1023
+
+// Division of n < 2^31 by a launch constant: pow2 ? n >> shift : mulhi(n, mul) >> shift, with
+// mul = ceil(2^(32+shift) / d), shift = floor(log2 d) (exact for every n < 2^31; r1_capi.cpp).
+struct R1FastDiv
+{
+    uint32_t mul, shift, pow2;
+};
 
 // Everything the trace kernel needs; passed by value (kernarg segment => SGPRs).
 struct R1DeviceScene
@@ -23,7 +31,7 @@ struct R1DeviceScene
     // {type, param}.
     const float4 *exact;
     const float4 *shade;   // {inv_radius, albedo_r, albedo_g, albedo_b}
-    const float2 *mat;     // {bit_cast<float>(type), param}
+    const float4 *mat;     // {bit_cast<float>(type), param, 1/ref_idx, ((1-ref)/(1+ref))^2} (last two: dielectrics)
     uint32_t n_active;     // real entries
     uint32_t n_sweep;      // padded to a multiple of 16 (the table holds 8 more for the prefetch)
 };
@@ -44,8 +52,13 @@ struct R1TraceArgs
     int32_t tile_w, tile_h, tiles_x;
     int32_t shard, num_shards;
     uint32_t n_local_tiles;      // tiles this shard owns
-    const uint32_t *tile_sample_base; // [n_local_tiles + 1] prefix sums of samples per local tile
-    uint32_t total_samples;      // tile_sample_base[n_local_tiles]
+    // Sample slots are enumerated over PADDED tiles: slot k = (local tile j, pixel in the
+    // tile_w x tile_h tile, sample s) = ((j * tile_h + ly) * tile_w + lx) * spp + s.  Slots of
+    // pixels outside the image (right/top edge tiles) are void: skipped by the tracer, never
+    // written, ignored by the resolve pass.
+    uint32_t full;               // tile_w * tile_h * spp slots per local tile
+    R1FastDiv div_full, div_spp, div_tw, div_tx; // by full, spp, tile_w, tiles_x
+    uint32_t total_samples;      // n_local_tiles * full (queue length)
     uint32_t *queue;             // global sample counter (zeroed before the launch)
     float4 *samples;             // [total_samples] {r, g, b, bit_cast<float>(rays)}
     unsigned long long *num_rays; // accumulated color() invocations
@@ -55,7 +68,7 @@ struct R1TraceArgs
 struct R1ResolveArgs
 {
     const float4 *samples;
-    const uint32_t *tile_sample_base;
+    uint32_t full;
     int32_t width, height, spp;
     int32_t tile_w, tile_h, tiles_x;
     int32_t shard, num_shards;

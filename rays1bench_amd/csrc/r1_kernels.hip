@@ -353,36 +353,37 @@ __device__ __forceinline__ uint32_t stack_get(const uint32_t *stack, int tid, in
     return (stack[w * R1_BLOCK + tid] >> sh) & 0x3FFu;
 }
 
-// k (local sample index) -> pixel, sample; then seeds + primary ray (rayweek1.cpp:759-760)
-__device__ __forceinline__ void start_sample(const R1TraceArgs &A, Path &p, uint32_t k)
+__device__ __forceinline__ uint32_t fastdiv(uint32_t n, const R1FastDiv dv)
 {
-    // tile lookup: largest j with base[j] <= k
-    uint32_t lo = 0, hi = A.n_local_tiles;
-    while (hi - lo > 1)
-    {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (A.tile_sample_base[mid] <= k)
-            lo = mid;
-        else
-            hi = mid;
-    }
-    const uint32_t tile = (uint32_t)A.shard + lo * (uint32_t)A.num_shards;
-    const int x0 = (int)(tile % (uint32_t)A.tiles_x) * A.tile_w;
-    const int y0 = (int)(tile / (uint32_t)A.tiles_x) * A.tile_h;
-    const int tw = min(A.tile_w, A.width - x0);
-    const uint32_t r = k - A.tile_sample_base[lo];
-    const uint32_t pix = r / (uint32_t)A.spp;
+    return dv.pow2 ? (n >> dv.shift) : (__umulhi(n, dv.mul) >> dv.shift);
+}
+
+// slot k -> (tile, pixel, sample); then seeds + primary ray (rayweek1.cpp:759-760).
+// Returns false for a void slot (pixel of an edge tile that lies outside the image).
+__device__ __forceinline__ bool start_sample(const R1TraceArgs &A, Path &p, uint32_t k)
+{
+    const uint32_t j = fastdiv(k, A.div_full);
+    const uint32_t r = k - j * A.full;
+    const uint32_t pix = fastdiv(r, A.div_spp);
     const uint32_t s = r - pix * (uint32_t)A.spp;
-    const int ly = (int)(pix / (uint32_t)tw);
-    const int x = x0 + (int)(pix - (uint32_t)ly * (uint32_t)tw);
-    const int y = y0 + ly;
+    const uint32_t ly = fastdiv(pix, A.div_tw);
+    const uint32_t lx = pix - ly * (uint32_t)A.tile_w;
+    const uint32_t tile = (uint32_t)A.shard + j * (uint32_t)A.num_shards;
+    const uint32_t ty = fastdiv(tile, A.div_tx);
+    const uint32_t tx = tile - ty * (uint32_t)A.tiles_x;
+    const int x = (int)(tx * (uint32_t)A.tile_w + lx);
+    const int y = (int)(ty * (uint32_t)A.tile_h + ly);
+    if (x >= A.width || y >= A.height)
+        return false;
 
     const r1_sample_seed sd = r1_seed_sample(A.seed, (uint32_t)(y * A.width + x), s);
     p.s_scalar = sd.scalar;
     p.s0 = sd.lane0;
     p.s1 = sd.lane1;
     p.s2 = sd.lane2;
-    p.k = k;
+    // output slot: samples are stored [tile][sample][pixel] so that the resolve pass reads
+    // coalesced (consecutive pixels of one sample index)
+    p.k = (j * (uint32_t)A.spp + s) * (uint32_t)(A.tile_w * A.tile_h) + pix;
     p.rays = 0;
     p.depth = 0;
     p.sp = 0;
@@ -410,6 +411,7 @@ __device__ __forceinline__ void start_sample(const R1TraceArgs &A, Path &p, uint
     const V3 dir =
         vsub(vsub(vadd(vadd(ld3(A.cam.lower_left), vscale(ld3(A.cam.horizontal), u)), vscale(ld3(A.cam.vertical), v)), org), offset);
     p.d = vunit(dir);
+    return true;
 }
 
 } // namespace
@@ -445,8 +447,12 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
     bool alive = false;
     unsigned long long lane_rays = 0;
 
-    // wave-uniform queue state
+    // wave-uniform queue state.  Chunks shrink as the queue drains (guided self-scheduling):
+    // a wave asks for ~1/(2*waves) of what it last saw remaining, between R1_CHUNK_MIN and
+    // R1_CHUNK samples, so that the last waves to finish hold little work.
     uint32_t q_next = 0, q_end = 0;
+    uint32_t q_remaining = A.total_samples;
+    const uint32_t n_waves2 = 2u * gridDim.x * (R1_BLOCK / 64);
     bool exhausted = false;
 
     for (;;)
@@ -461,9 +467,10 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
             {
                 if (exhausted)
                     break;
+                const uint32_t want = min((uint32_t)R1_CHUNK, max((uint32_t)R1_CHUNK_MIN, q_remaining / n_waves2));
                 uint32_t base = 0;
                 if (lane == 0)
-                    base = atomicAdd(A.queue, (uint32_t)R1_CHUNK);
+                    base = atomicAdd(A.queue, want);
                 base = __builtin_amdgcn_readfirstlane(base);
                 if (base >= A.total_samples)
                 {
@@ -471,15 +478,13 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
                     break;
                 }
                 q_next = base;
-                q_end = min(base + (uint32_t)R1_CHUNK, A.total_samples);
+                q_end = min(base + want, A.total_samples);
+                q_remaining = A.total_samples - q_end;
             }
             const uint32_t avail = q_end - q_next;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
             if (!alive && rank < avail)
-            {
-                start_sample(A, p, q_next + rank);
-                alive = true;
-            }
+                alive = start_sample(A, p, q_next + rank); // false: void slot, ask again
             q_next += min((uint32_t)__popcll(need), avail);
             need = __ballot(!alive);
         }
@@ -519,35 +524,29 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
                 if (p.depth < A.max_bounces)
                 {
                     // hit record (rayweek1.cpp:316-322)
-                    const float4 e = A.scene.exact[hit];
-                    const float4 sh = A.scene.shade[hit];
-                    const float2 mt = A.scene.mat[hit];
+                    const f4 e = ((const f4 *)A.scene.exact)[hit];
+                    const f4 sh = ((const f4 *)A.scene.shade)[hit];
+                    const f4 mt = ((const f4 *)A.scene.mat)[hit];
                     const V3 hp = vadd(p.o, vscale(p.d, t_hit));
                     const V3 n = vscale(vsub(hp, mk(e.x, e.y, e.z)), sh.x);
                     const uint32_t type = __float_as_uint(mt.x);
+                    // Lambertian and Metal both draw random_in_unit_sphere from the x4 stream
+                    // (rayweek1.cpp:405, :430; Metal even with fuzz == 0): one shared loop
+                    V3 rius = mk(0, 0, 0);
+                    if (type != 2u)
+                        rius = random_in_unit_sphere(p);
+                    V3 dir; // un-normalised scattered direction; Ray::Ray normalises (rayweek1.cpp:107)
                     if (type == 0u)
                     {
                         // Lambertian::scatter rayweek1.cpp:403-409
-                        const V3 target = vadd(vadd(hp, n), random_in_unit_sphere(p));
-                        p.d = vunit(vsub(target, hp));
-                        p.o = hp;
-                        stack_push(s_stack, tid, p.sp, (uint32_t)hit);
-                        ++p.sp;
+                        const V3 target = vadd(vadd(hp, n), rius);
+                        dir = vsub(target, hp);
                     }
                     else if (type == 1u)
                     {
                         // Metal::scatter rayweek1.cpp:427-433; reflect :414-417
                         const V3 refl = vsub(p.d, vscale(n, 2.0f * vdot(p.d, n)));
-                        const V3 nd = vunit(vadd(refl, vscale(random_in_unit_sphere(p), mt.y)));
-                        p.o = hp;
-                        p.d = nd;
-                        if (vdot(nd, n) > 0)
-                        {
-                            stack_push(s_stack, tid, p.sp, (uint32_t)hit);
-                            ++p.sp;
-                        }
-                        else
-                            done = true; // scatter() == false -> Vec3(0,0,0), rayweek1.cpp:528
+                        dir = vadd(refl, vscale(rius, mt.y));
                     }
                     else
                     {
@@ -566,7 +565,7 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
                         else
                         {
                             outward = n;
-                            ni_over_nt = ieee_div(1.0f, ref_idx);
+                            ni_over_nt = mt.z; // 1.0f / _refIdx, divided on the host (same IEEE division)
                             cosine = -ddn;
                         }
                         // refract rayweek1.cpp:439-452
@@ -577,15 +576,25 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
                         if (discriminant > 0)
                         {
                             refracted = vsub(vscale(vsub(p.d, vscale(outward, dt)), ni_over_nt), vscale(outward, ieee_sqrt(discriminant)));
-                            // schlick rayweek1.cpp:454-459
-                            float r0 = ieee_div(1.0f - ref_idx, 1.0f + ref_idx);
-                            r0 = r0 * r0;
+                            // schlick rayweek1.cpp:454-459; r0 = ((1 - ref)/(1 + ref))^2 comes from the host
+                            const float r0 = mt.w;
                             reflect_prob = r0 + (1.0f - r0) * pow5(1.0f - cosine);
                         }
-                        const V3 nd = (rand01(p.s_scalar) < reflect_prob) ? reflected : refracted;
-                        p.o = hp;
-                        p.d = vunit(nd);
+                        dir = (rand01(p.s_scalar) < reflect_prob) ? reflected : refracted;
                     }
+                    const V3 nd = vunit(dir);
+                    p.o = hp;
+                    p.d = nd;
+                    if (type == 2u || type == 0u || vdot(nd, n) > 0)
+                    {
+                        if (type != 2u)
+                        {
+                            stack_push(s_stack, tid, p.sp, (uint32_t)hit);
+                            ++p.sp;
+                        }
+                    }
+                    else
+                        done = true; // Metal::scatter() == false -> Vec3(0,0,0), rayweek1.cpp:432, :528
                     ++p.depth;
                 }
                 else
@@ -652,14 +661,19 @@ __global__ void __launch_bounds__(256) r1_resolve_kernel(const R1ResolveArgs A)
         const int y0 = (int)(tile / (uint32_t)A.tiles_x) * A.tile_h;
         const int tw = min(A.tile_w, A.width - x0);
         const int th = min(A.tile_h, A.height - y0);
-        const uint32_t base = A.tile_sample_base[lt];
-        for (uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x; pix < (uint32_t)(tw * th); pix += gridDim.x * blockDim.x)
+        const uint32_t base = lt * A.full;
+        for (uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x; pix < (uint32_t)(A.tile_w * A.tile_h); pix += gridDim.x * blockDim.x)
         {
-            const float4 *s = A.samples + base + pix * (uint32_t)A.spp;
+            const int ly = (int)(pix / (uint32_t)A.tile_w);
+            const int lx = (int)(pix - (uint32_t)ly * (uint32_t)A.tile_w);
+            if (lx >= tw || ly >= th)
+                continue; // void slots of an edge tile
+            const uint32_t tile_px = (uint32_t)(A.tile_w * A.tile_h);
+            const float4 *s = A.samples + base + pix; // [tile][sample][pixel]
             float cr = 0, cg = 0, cb = 0;
             for (int i = 0; i < A.spp; ++i)
             {
-                const float4 v = s[i];
+                const float4 v = s[(size_t)i * tile_px];
                 cr += v.x, cg += v.y, cb += v.z; // col += color(...) rayweek1.cpp:762
             }
             cr *= A.inv_spp, cg *= A.inv_spp, cb *= A.inv_spp;
@@ -667,8 +681,6 @@ __global__ void __launch_bounds__(256) r1_resolve_kernel(const R1ResolveArgs A)
             const uint8_t r = (uint8_t)(int)(cr * 255.99f);
             const uint8_t g = (uint8_t)(int)(cg * 255.99f);
             const uint8_t b = (uint8_t)(int)(cb * 255.99f);
-            const int ly = (int)(pix / (uint32_t)tw);
-            const int lx = (int)(pix - (uint32_t)ly * (uint32_t)tw);
             size_t o;
             if (A.block_layout)
                 o = ((size_t)lt * A.tile_h * A.tile_w + (size_t)ly * A.tile_w + lx) * 3;

@@ -1,0 +1,82 @@
+"""world_size-2 (and 3) gloo tests of the N > 1 path on CPU: the tile -> rank split, the dense
+block layout, the all-gather + all-reduce exchange step (rays1bench_amd.sharding.gather_blocks,
+the same function bench.py calls with RCCL) and the assembly.  The device kernels cannot run
+here, so each rank fills its block with the ORACLE's render of exactly its shard; the checker
+is the oracle's render of the whole frame."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist  # noqa: E402
+import torch.multiprocessing as mp  # noqa: E402
+
+import rays1bench_amd as r1  # noqa: E402
+from rays1bench_amd import binding, sharding  # noqa: E402
+import r1o  # noqa: E402
+
+W, H, SPP, SEED = 150, 100, 2, 77
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc = r1.create_medium_scene(W, H)
+        sa = r1o.SceneArrays.from_c(sc.spheres, sc.camera)
+        # this rank's tiles only (oracle honours shard/num_shards exactly like r1_render)
+        part, part_rays, _ = r1o.render_frame(sa, r1o.make_params(W, H, SPP, SEED, shard=rank, num_shards=world), nthreads=2)
+        p = r1.make_params(W, H, SPP, SEED, shard=rank, num_shards=world)
+        nbytes = binding.shard_block_bytes(p)
+        assert nbytes == sharding.block_bytes(W, H, world)
+        block = torch.from_numpy(sharding.pack_block(part, rank, world))
+        assert block.numel() == nbytes
+        gathered = torch.zeros(world * nbytes, dtype=torch.uint8)
+        rays = torch.tensor([part_rays], dtype=torch.int64)
+        sharding.gather_blocks(dist, block, gathered, rays)
+        img = sharding.assemble(gathered.numpy(), W, H, world)
+        full, full_rays, _ = r1o.render_frame(sa, r1o.make_params(W, H, SPP, SEED), nthreads=2)
+        assert int(rays.item()) == full_rays
+        assert img.tobytes() == full.tobytes()
+        # every pixel belongs to exactly one rank
+        mine = np.zeros((H, W), np.int64)
+        tx, _ = sharding.tiles(W, H)
+        for t in sharding.shard_tiles(W, H, rank, world):
+            mine[(t // tx) * 32:(t // tx) * 32 + 32, (t % tx) * 32:(t % tx) * 32 + 32] += 1
+        cover = torch.from_numpy(mine)
+        dist.all_reduce(cover)
+        assert (cover.numpy() == 1).all()
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tile_split_gather_assemble_gloo(world, tmp_path):
+    mp.spawn(_rank_main, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]
+
+
+def test_sharding_helpers_match_c_abi():
+    for (w, h, n) in [(1200, 800, 8), (1200, 800, 1), (77, 45, 3), (31, 33, 2), (1920, 1080, 8)]:
+        p = r1.make_params(w, h, 1, shard=0, num_shards=n)
+        total, per = binding.tile_count(p)
+        tx, ty = sharding.tiles(w, h)
+        assert total == tx * ty and per == sharding.tiles_per_shard(w, h, n)
+        assert binding.shard_block_bytes(p) == sharding.block_bytes(w, h, n)
+        # pack / assemble round trip
+        rng = np.random.default_rng(w + h + n)
+        img = rng.integers(1, 255, (h, w, 3), dtype=np.uint8)
+        blocks = np.concatenate([sharding.pack_block(img, s, n) for s in range(n)])
+        assert sharding.assemble(blocks, w, h, n).tobytes() == img.tobytes()
