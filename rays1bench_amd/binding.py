@@ -242,7 +242,12 @@ class Renderer:
         _check(lib().r1_last_stats(self._c, out))
         names = ["wave_iterations", "alive_lanes", "candidate_loop_trips", "overflow_lanes", "cycles_refill", "cycles_pass1",
                  "cycles_candidates", "cycles_shade", "cycles_wave", "candidates"]
-        return {n: int(out[i]) for i, n in enumerate(names)}
+        d = {n: int(out[i]) for i, n in enumerate(names)}
+        m = (1 << 64) - 1
+        d["longest_wave_cycles"] = int(out[10])
+        d["shortest_wave_cycles"] = m - int(out[11])
+        d["span_cycles"] = int(out[12]) - (m - int(out[13]))
+        return d
 
     def launch_info(self):
         li = LaunchInfo()

@@ -490,6 +490,20 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
         }
         if (__ballot(alive) == 0ull)
             break;
+        // A frame's critical path is its longest bounce chain (up to 51 dependent sweeps, ~1/3 of
+        // a 10-spp frame when the wave shares its SIMD with three others).  Waves that carry a
+        // deep path ask for issue priority so that the chain finishes before the queue runs dry.
+        {
+            const int prio = __ballot(alive && p.depth >= 36) ? 3 : __ballot(alive && p.depth >= 24) ? 2 : __ballot(alive && p.depth >= 12) ? 1 : 0;
+            if (prio == 3)
+                __builtin_amdgcn_s_setprio(3);
+            else if (prio == 2)
+                __builtin_amdgcn_s_setprio(2);
+            else if (prio == 1)
+                __builtin_amdgcn_s_setprio(1);
+            else
+                __builtin_amdgcn_s_setprio(0);
+        }
         if (STATS)
         {
             wstat[4] += __builtin_readcyclecounter() - wstat[15];
@@ -635,8 +649,14 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
             c9 += __shfl_down(c9, off, 64);
         wstat[9] = c9;
         if (lane == 0 && A.stats)
+        {
             for (int i = 0; i < 10; ++i)
                 atomicAdd(&A.stats[i], wstat[i]);
+            atomicMax(&A.stats[10], wstat[8]);                      // longest wave (cycles)
+            atomicMax(&A.stats[11], ~wstat[8]);                     // ~shortest wave
+            atomicMax(&A.stats[12], (unsigned long long)__builtin_readcyclecounter());  // last wave end (this XCD's counter)
+            atomicMax(&A.stats[13], ~wstat[14]);                    // ~first wave start
+        }
     }
 
     // ray count: wave reduction, one atomic per wave (rayweek1.cpp:809-813)

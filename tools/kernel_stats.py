@@ -30,6 +30,8 @@ for k in ("cycles_refill", "cycles_pass1", "cycles_candidates", "cycles_shade"):
     st["share_" + k[7:]] = st[k] / st["cycles_wave"]
 st["cycles_per_iteration"] = st["cycles_wave"] / st["wave_iterations"]
 st["pass1_cycles_per_iteration"] = st["cycles_pass1"] / st["wave_iterations"]
+st["mean_wave_cycles"] = st["cycles_wave"] / waves
+st["wave_slot_utilisation"] = st["mean_wave_cycles"] / max(st["span_cycles"], 1)
 st["candidates_per_ray"] = st["candidates"] / rays
 st["candidate_trips_per_iteration"] = st["candidate_loop_trips"] / st["wave_iterations"]
 print(json.dumps(st, indent=1))
