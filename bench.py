@@ -24,7 +24,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SCENE_KIND = {"small": 0, "medium": 1, "large": 2}
+SCENE_KIND = {"small": 0, "medium": 1, "large": 2, "grid": 3}
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_VECTOR_PEAK_TF = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
 
@@ -84,14 +84,21 @@ def main():
     ap.add_argument("--width", type=int, default=1200)
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--spp", type=int, default=10)
+    ap.add_argument("--grid", default="400x250", help="with --scene grid: small-sphere lattice WxH (BASELINE config 5: 400x250)")
     ap.add_argument("--seed", type=int, default=10001)
     ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--inflight", type=int, default=4,
-                    help="frames in flight (each on its own stream + context workspace); 2 lets the next frame's "
-                         "workgroups fill the CUs that the current frame's last long paths leave idle")
+    ap.add_argument("--inflight", type=int, default=16,
+                    help="frames in flight, each on its own stream + context workspace: later frames' workgroups fill "
+                         "the CUs that a frame's last long bounce chains leave idle (1 = one frame at a time)")
+    ap.add_argument("--emulate-shards", type=int, default=0,
+                    help="tuning aid: render only shard 0 of K on one GPU, no collective (per-rank load of a K-GPU run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # Frames in flight only overlap when their streams sit on different hardware queues; the
+    # ROCm default is 4 (measured: 16 queues + 16 frames in flight reach 98 % / 91 % of the ideal
+    # per-rank frame time at 1/2/4 and 8 shards, 4 queues 78 % / 66 %).  Must be set before HIP starts.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import torch
     import rays1bench_amd as r1
     from rays1bench_amd import binding, sharding
@@ -116,6 +123,8 @@ def main():
     w, h, spp = args.width, args.height, args.spp
     dev = torch.device("cuda", local_rank)
     p = r1.make_params(w, h, spp, args.seed, shard=rank, num_shards=n, variant=args.variant)
+    if args.emulate_shards > 1 and n == 1:
+        p = r1.make_params(w, h, spp, args.seed, shard=0, num_shards=args.emulate_shards, variant=args.variant)
     block_bytes = binding.shard_block_bytes(p)
 
     class Slot:
@@ -123,10 +132,12 @@ def main():
 
         def __init__(self):
             self.rend = r1.Renderer(local_rank)
-            self.scene = r1.Scene(SCENE_KIND[args.scene], w, h)
+            gw, gh = (int(v) for v in args.grid.split("x")) if args.scene == "grid" else (0, 0)
+            self.scene = r1.Scene(SCENE_KIND[args.scene], w, h, gw, gh)
             self.rend.set_scene(self.scene)
             self.block = torch.zeros(block_bytes, dtype=torch.uint8, device=dev)
-            self.gathered = torch.zeros(n * block_bytes, dtype=torch.uint8, device=dev) if n > 1 else self.block
+            self.gathered = torch.zeros(max(n, args.emulate_shards) * block_bytes, dtype=torch.uint8, device=dev) \
+                if max(n, args.emulate_shards) > 1 else self.block
             self.rays = torch.zeros(1, dtype=torch.int64, device=dev)
             self.image = torch.zeros((h, w, 3), dtype=torch.uint8, device=dev)
             self.stream = torch.cuda.Stream(device=dev)
@@ -239,7 +250,7 @@ def main():
             for _ in range(reps):
                 tot += rend.render_into(ph, host)[0]
             out["pcie_inclusive_mrays_per_s"] = tot / (time.perf_counter() - t1) / 1e6
-            if not args.no_cpu_baseline:
+            if not args.no_cpu_baseline and args.scene != "grid":
                 try:
                     out["cpu_baseline"] = cpu_baseline(args.scene, w, h, spp)
                 except Exception as e:  # the baseline is reported, never required

@@ -22,7 +22,7 @@ extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int 
 extern "C" hipError_t r1_launch_resolve(const R1ResolveArgs *args, hipStream_t stream);
 extern "C" hipError_t r1_launch_assemble(const void *blocks, void *rgb, int width, int height, int tile_w, int tile_h, int tiles_x,
                                          int tiles_total, int num_shards, int tiles_per_shard, hipStream_t stream);
-extern "C" hipError_t r1_trace_occupancy(int variant, int *blocks_per_cu);
+extern "C" hipError_t r1_trace_occupancy(int variant, int big, int *blocks_per_cu);
 extern "C" int r1_params_check(const r1_params *p); // r1_host.cpp
 
 // ---- errors ---------------------------------------------------------------------------------
@@ -84,7 +84,8 @@ struct r1_context
     bool tile_key_valid = false;
     uint32_t n_local_tiles = 0, total_samples = 0, full = 0;
 
-    int occupancy[4] = {0, 0, 0, 0}; // blocks per CU of the trace kernel, by variant
+    int occupancy[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // [variant + 4*big]
+    DevBuf gstack; // blocks per CU of the trace kernel, by variant
 
     r1_launch_info info;
 };
@@ -179,7 +180,7 @@ extern "C" void r1_destroy(r1_context *c)
     if (c->stream)
         (void)hipStreamSynchronize(c->stream);
     release(c->sweep), release(c->exact), release(c->shade), release(c->mat);
-    release(c->counters), release(c->samples), release(c->image);
+    release(c->gstack), release(c->counters), release(c->samples), release(c->image);
     for (hipEvent_t e : c->ring)
         (void)hipEventDestroy(e);
     if (c->ev0)
@@ -228,9 +229,9 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
             c->active_to_scene.push_back(i);
         }
     const uint32_t na = (uint32_t)c->active_to_scene.size();
-    if (na > R1_MAX_ACTIVE_10BIT)
+    if (na > R1_MAX_ACTIVE)
     {
-        r1_set_error("r1_set_scene: %u hittable spheres; this build supports up to %d", na, R1_MAX_ACTIVE_10BIT);
+        r1_set_error("r1_set_scene: %u hittable spheres; this build supports up to %u", na, R1_MAX_ACTIVE);
         return R1_ELIMIT;
     }
     const uint32_t ns = (na + 15u) & ~15u; // the sweep evaluates two 8-sphere chunks per loop trip
@@ -385,15 +386,21 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     a.num_rays = (unsigned long long *)d_rays;
     a.stats = variant == 3 ? (unsigned long long *)((char *)c->counters.p + 128) : nullptr;
 
-    if (c->occupancy[variant] == 0)
-        R1_HIP(r1_trace_occupancy(variant, &c->occupancy[variant]));
-    int per_cu = c->occupancy[variant];
+    const int big = c->n_active > R1_MAX_ACTIVE_10BIT ? 1 : 0;
+    if (c->occupancy[variant + 4 * big] == 0)
+        R1_HIP(r1_trace_occupancy(variant, big, &c->occupancy[variant + 4 * big]));
+    int per_cu = c->occupancy[variant + 4 * big];
     if (per_cu < 1)
         per_cu = 1;
     if (per_cu > 8)
         per_cu = 8;
+    // Persistent grid.  A wave's lanes run dry one by one at the end of its share (the longest
+    // bounce chain of 64 lanes is ~20 sweeps), so a wave needs many times that much work to stay
+    // full: give every lane >= R1_SAMPLES_PER_LANE samples and let concurrent frames (other
+    // streams) fill the CUs a small frame leaves free.
     long long blocks = (long long)c->cus * per_cu;
-    const long long needed = ((long long)c->total_samples + R1_BLOCK - 1) / R1_BLOCK;
+    static const long long spl = getenv("R1_SAMPLES_PER_LANE") ? atoll(getenv("R1_SAMPLES_PER_LANE")) : R1_SAMPLES_PER_LANE;
+    const long long needed = ((long long)c->total_samples + R1_BLOCK * spl - 1) / (R1_BLOCK * spl);
     if (blocks > needed)
         blocks = needed;
     if (blocks < 1)
@@ -406,6 +413,12 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
         e0 = c->ring[3 * slot], e1 = c->ring[3 * slot + 1], e2 = c->ring[3 * slot + 2];
         if (c->ring_used < c->ring_frames)
             ++c->ring_used;
+    }
+    if (big)
+    {
+        if ((rc = ensure(c->gstack, (size_t)R1_STACK_ENTRIES * (size_t)blocks * R1_BLOCK * 4)))
+            return rc;
+        a.gstack = (uint32_t *)c->gstack.p;
     }
     R1_HIP(hipMemsetAsync(c->counters.p, 0, 64, st));
     if (variant == 3)

@@ -11,7 +11,10 @@
 #define R1_STACK_WORDS 17   // ceil(51 / 3) packed 10-bit hit indices per lane (max_bounces <= 51)
 #define R1_CHUNK 256        // most samples a wave takes from the global queue per atomic
 #define R1_CHUNK_MIN 32      // fewest (end of the queue: guided self-scheduling)
+#define R1_SAMPLES_PER_LANE 48 // grid sizing: samples each lane should get (see enqueue_frame)
 #define R1_MAX_ACTIVE_10BIT 1023
+#define R1_MAX_ACTIVE (1u << 21) // big-scene kernels: 26-bit pair indices, limit kept at 2 M spheres
+#define R1_STACK_ENTRIES 51
 
 // Division of n < 2^31 by a launch constant: pow2 ? n >> shift : mulhi(n, mul) >> shift, with
 // mul = ceil(2^(32+shift) / d), shift = floor(log2 d) (exact for every n < 2^31; r1_capi.cpp).
@@ -62,6 +65,7 @@ struct R1TraceArgs
     uint32_t *queue;             // global sample counter (zeroed before the launch)
     float4 *samples;             // [total_samples] {r, g, b, bit_cast<float>(rays)}
     unsigned long long *num_rays; // accumulated color() invocations
+    uint32_t *gstack;             // big scenes: attenuation stack [R1_STACK_ENTRIES][grid threads], else null
     unsigned long long *stats;    // diagnostic counters (R1_VARIANT_STATS builds only), else null
 };
 

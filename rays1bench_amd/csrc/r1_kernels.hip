@@ -89,6 +89,17 @@ __device__ __forceinline__ uint32_t xorshift32(uint32_t &state)
 __device__ __forceinline__ float rand01(uint32_t &s) { return (float)(xorshift32(s) & 0xFFFFFFu) * (1.0f / 16777216.0f); }
 __device__ __forceinline__ float rand02(uint32_t &s) { return (float)(xorshift32(s) & 0xFFFFFFu) * (1.0f / 8388608.0f); }
 
+template <bool BIG>
+struct IdxType
+{
+    typedef uint16_t type;
+};
+template <>
+struct IdxType<true>
+{
+    typedef uint32_t type;
+};
+
 struct Path
 {
     V3 o, d;                        // Ray::_origin, Ray::_dir (unit)
@@ -201,11 +212,14 @@ __device__ __forceinline__ float exact_offer(const f4 e, const V3 o, const V3 d)
 // lane comes next: ~3 full-width trips instead of ~9 mostly-empty ones.  Offers are combined
 // per ray with a 64-bit LDS atomic min on {t bits, sphere index}: closest hit, ties to the
 // lowest index — the reference's rule.  Must be called by ALL 64 lanes (full EXEC).
-template <bool STATS>
-__device__ __forceinline__ void cooperative_exact(const R1DeviceScene &S, const V3 o, const V3 d, int cnt, const uint16_t *cand,
-                                                  uint16_t *pairs /* this wave's [R1_PAIR_CAP] */, unsigned long long *best /* this wave's [64] */,
+// IDX = uint16_t (<= 1023 active spheres: 6 lane bits + 10 index bits per pair) or uint32_t
+// (big scenes: 6 + 26 bits).
+template <bool STATS, typename IDX>
+__device__ __forceinline__ void cooperative_exact(const R1DeviceScene &S, const V3 o, const V3 d, int cnt, const IDX *cand,
+                                                  IDX *pairs /* this wave's [R1_PAIR_CAP] */, unsigned long long *best /* this wave's [64] */,
                                                   const int tid, const int lane, unsigned long long *wstat)
 {
+    constexpr int IDX_BITS = sizeof(IDX) == 2 ? 10 : 26;
     // exclusive prefix sum of cnt over the wave
     int incl = cnt;
 #pragma unroll
@@ -218,7 +232,7 @@ __device__ __forceinline__ void cooperative_exact(const R1DeviceScene &S, const 
     const int total = __builtin_amdgcn_readlane(incl, 63);
     const int excl = incl - cnt;
     for (int j = 0; j < cnt; ++j)
-        pairs[excl + j] = (uint16_t)(((uint32_t)lane << 10) | cand[j * R1_BLOCK + tid]);
+        pairs[excl + j] = (IDX)(((uint32_t)lane << IDX_BITS) | (uint32_t)cand[j * R1_BLOCK + tid]);
     __builtin_amdgcn_wave_barrier();
     if (STATS)
         wstat[2] += (unsigned long long)((total + 63) >> 6);
@@ -226,9 +240,9 @@ __device__ __forceinline__ void cooperative_exact(const R1DeviceScene &S, const 
     {
         const int j = base + lane;
         const bool have = j < total;
-        const uint32_t pr = have ? (uint32_t)pairs[j] : ((uint32_t)lane << 10);
-        const int owner = (int)(pr >> 10);
-        const uint32_t idx = pr & 1023u;
+        const uint32_t pr = have ? (uint32_t)pairs[j] : ((uint32_t)lane << IDX_BITS);
+        const int owner = (int)(pr >> IDX_BITS);
+        const uint32_t idx = pr & ((1u << IDX_BITS) - 1u);
         V3 ro, rd;
         ro.x = __shfl(o.x, owner, 64), ro.y = __shfl(o.y, owner, 64), ro.z = __shfl(o.z, owner, 64);
         rd.x = __shfl(d.x, owner, 64), rd.y = __shfl(d.y, owner, 64), rd.z = __shfl(d.z, owner, 64);
@@ -245,14 +259,14 @@ __device__ __forceinline__ void cooperative_exact(const R1DeviceScene &S, const 
 // ---- sweep, prefilter form -----------------------------------------------------------------
 // (formula and slack: see the comment block above)  Called by all 64 lanes; lanes with
 // alive == false never flag a candidate but help in the cooperative exact phase.
-template <bool STATS>
+template <bool STATS, typename IDX>
 __device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const bool alive, const V3 o, const V3 d, float &t_max,
-                                                int &hit_index, uint16_t *cand /* [R1_CAND_CAP][R1_BLOCK] */,
-                                                uint16_t *pairs /* [R1_BLOCK/64][R1_PAIR_CAP] */,
+                                                int &hit_index, IDX *cand /* [R1_CAND_CAP][R1_BLOCK] */,
+                                                IDX *pairs /* [R1_BLOCK/64][R1_PAIR_CAP] */,
                                                 unsigned long long *best /* [R1_BLOCK] */, const int tid, unsigned long long *wstat)
 {
     const int lane = tid & 63;
-    uint16_t *wpairs = pairs + (tid >> 6) * R1_PAIR_CAP;
+    IDX *wpairs = pairs + (tid >> 6) * R1_PAIR_CAP;
     unsigned long long *wbest = best + (tid & ~63);
     const unsigned long long NONE = ~0ull;
 
@@ -296,12 +310,12 @@ __device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const bo
             /* a chunk adds at most 8 entries per lane: make room first, then append unchecked */                      \
             if (__ballot(cnt > R1_CAND_CAP - 8))                                                                       \
             {                                                                                                          \
-                cooperative_exact<STATS>(S, o, d, cnt, cand, wpairs, wbest, tid, lane, wstat);                         \
+                cooperative_exact<STATS, IDX>(S, o, d, cnt, cand, wpairs, wbest, tid, lane, wstat);                    \
                 cnt = 0;                                                                                               \
             }                                                                                                          \
             _Pragma("unroll") for (int u = 0; u < 8; ++u) if (c[u])                                                    \
             {                                                                                                          \
-                cand[cnt * R1_BLOCK + tid] = (uint16_t)(8 * (CH) + u);                                                 \
+                cand[cnt * R1_BLOCK + tid] = (IDX)(8 * (CH) + u);                                                      \
                 ++cnt;                                                                                                 \
             }                                                                                                          \
         }                                                                                                              \
@@ -330,7 +344,7 @@ __device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const bo
         wstat[15] = __builtin_readcyclecounter();
         wstat[9] += (unsigned long long)cnt; // per-lane (summed over lanes at the end)
     }
-    cooperative_exact<STATS>(S, o, d, cnt, cand, wpairs, wbest, tid, lane, wstat);
+    cooperative_exact<STATS, IDX>(S, o, d, cnt, cand, wpairs, wbest, tid, lane, wstat);
     const unsigned long long key = wbest[lane];
     if (key != NONE)
     {
@@ -339,16 +353,27 @@ __device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const bo
     }
 }
 
-// packed attenuation stack: three 10-bit sphere indices per LDS word
-__device__ __forceinline__ void stack_push(uint32_t *stack, int tid, int sp, uint32_t idx)
+// Attenuation stack.  Small scenes: packed in LDS, three 10-bit sphere indices per word.  Big
+// scenes (> 1023 active spheres): one u32 per entry in a global workspace laid out
+// [entry][global thread] (coalesced); its traffic is nothing next to a 100 k-sphere sweep.
+template <bool BIG>
+__device__ __forceinline__ void stack_push(uint32_t *stack, uint32_t *gstack, uint32_t gstride, uint32_t gtid, int tid, int sp, uint32_t idx)
 {
+    if (BIG)
+    {
+        gstack[(size_t)sp * gstride + gtid] = idx;
+        return;
+    }
     const int w = sp / 3, sh = (sp - 3 * w) * 10;
     uint32_t v = stack[w * R1_BLOCK + tid];
     v = (v & ~(0x3FFu << sh)) | (idx << sh);
     stack[w * R1_BLOCK + tid] = v;
 }
-__device__ __forceinline__ uint32_t stack_get(const uint32_t *stack, int tid, int e)
+template <bool BIG>
+__device__ __forceinline__ uint32_t stack_get(const uint32_t *stack, const uint32_t *gstack, uint32_t gstride, uint32_t gtid, int tid, int e)
 {
+    if (BIG)
+        return gstack[(size_t)e * gstride + gtid];
     const int w = e / 3, sh = (e - 3 * w) * 10;
     return (stack[w * R1_BLOCK + tid] >> sh) & 0x3FFu;
 }
@@ -422,9 +447,10 @@ __device__ __forceinline__ bool start_sample(const R1TraceArgs &A, Path &p, uint
 // ============================================================================================
 // STATS = diagnostic build (variant R1_VARIANT_STATS): same results, plus per-phase cycle and
 // utilisation counters in A.stats; never used by the product path.
-template <int VARIANT, bool STATS>
+template <int VARIANT, bool STATS, bool BIG>
 __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
 {
+    typedef typename IdxType<BIG>::type IDX;
     unsigned long long wstat[16];
     if (STATS)
     {
@@ -432,9 +458,10 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
             wstat[i] = 0;
         wstat[14] = __builtin_readcyclecounter();
     }
-    __shared__ uint32_t s_stack[R1_STACK_WORDS * R1_BLOCK];
-    __shared__ uint16_t s_cand[R1_CAND_CAP * R1_BLOCK];
-    __shared__ uint16_t s_pairs[(R1_BLOCK / 64) * R1_PAIR_CAP];
+    __shared__ uint32_t s_stack[BIG ? 1 : R1_STACK_WORDS * R1_BLOCK];
+    __shared__ IDX s_cand[R1_CAND_CAP * R1_BLOCK];
+    __shared__ IDX s_pairs[(R1_BLOCK / 64) * R1_PAIR_CAP];
+    const uint32_t gstride = gridDim.x * R1_BLOCK, gtid = blockIdx.x * R1_BLOCK + threadIdx.x;
     __shared__ unsigned long long s_best[R1_BLOCK];
 
     const int tid = (int)threadIdx.x;
@@ -521,7 +548,7 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
                 sweep_reference(A.scene, p.o, p.d, t_hit, hit);
         }
         else
-            sweep_prefilter<STATS>(A.scene, alive, p.o, p.d, t_hit, hit, s_cand, s_pairs, s_best, tid, wstat);
+            sweep_prefilter<STATS, IDX>(A.scene, alive, p.o, p.d, t_hit, hit, s_cand, s_pairs, s_best, tid, wstat);
         if (STATS)
         {
             wstat[6] += __builtin_readcyclecounter() - wstat[15];
@@ -603,7 +630,7 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
                     {
                         if (type != 2u)
                         {
-                            stack_push(s_stack, tid, p.sp, (uint32_t)hit);
+                            stack_push<BIG>(s_stack, A.gstack, gstride, gtid, tid, p.sp, (uint32_t)hit);
                             ++p.sp;
                         }
                     }
@@ -623,7 +650,7 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
                 // unwind: attenuation * color(...) innermost first (rayweek1.cpp:525)
                 for (int e = p.sp - 1; e >= 0; --e)
                 {
-                    const float4 sh = A.scene.shade[stack_get(s_stack, tid, e)];
+                    const float4 sh = A.scene.shade[stack_get<BIG>(s_stack, A.gstack, gstride, gtid, tid, e)];
                     col = mk(sh.y * col.x, sh.z * col.y, sh.w * col.z);
                 }
                 done = true;
@@ -736,12 +763,17 @@ __global__ void __launch_bounds__(256)
 
 extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int blocks, hipStream_t stream)
 {
-    if (variant == 1)
-        hipLaunchKernelGGL((r1_trace_kernel<1, false>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
-    else if (variant == 3)
-        hipLaunchKernelGGL((r1_trace_kernel<2, true>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
+    const bool big = args->scene.n_active > R1_MAX_ACTIVE_10BIT;
+    if (variant == 1 && big)
+        hipLaunchKernelGGL((r1_trace_kernel<1, false, true>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
+    else if (variant == 1)
+        hipLaunchKernelGGL((r1_trace_kernel<1, false, false>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
+    else if (variant == 3 && !big)
+        hipLaunchKernelGGL((r1_trace_kernel<2, true, false>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
+    else if (big)
+        hipLaunchKernelGGL((r1_trace_kernel<2, false, true>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
     else
-        hipLaunchKernelGGL((r1_trace_kernel<2, false>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
+        hipLaunchKernelGGL((r1_trace_kernel<2, false, false>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
     return hipGetLastError();
 }
 
@@ -766,11 +798,15 @@ extern "C" hipError_t r1_launch_assemble(const void *blocks, void *rgb, int widt
     return hipGetLastError();
 }
 
-extern "C" hipError_t r1_trace_occupancy(int variant, int *blocks_per_cu)
+extern "C" hipError_t r1_trace_occupancy(int variant, int big, int *blocks_per_cu)
 {
+    if (variant == 1 && big)
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<1, false, true>, R1_BLOCK, 0);
     if (variant == 1)
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<1, false>, R1_BLOCK, 0);
-    if (variant == 3)
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<2, true>, R1_BLOCK, 0);
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<2, false>, R1_BLOCK, 0);
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<1, false, false>, R1_BLOCK, 0);
+    if (variant == 3 && !big)
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<2, true, false>, R1_BLOCK, 0);
+    if (big)
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<2, false, true>, R1_BLOCK, 0);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<2, false, false>, R1_BLOCK, 0);
 }

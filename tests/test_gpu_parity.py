@@ -238,3 +238,40 @@ def test_device_resident_shard_and_assemble(renderer):
     assert out.cpu().numpy().tobytes() == full.tobytes()
     t_trace, t_total = renderer.last_timing()
     assert 0 < t_trace <= t_total
+
+
+# ---- big scenes (BASELINE config 5 shape: the large generator scaled up) -------------------------
+
+
+@pytest.mark.parametrize("gw,gh,w,h,spp", [(64, 40, 160, 120, 4), (33, 31, 96, 64, 3)])
+def test_big_scene_kernels_bit_exact_vs_oracle(renderer, gw, gh, w, h, spp):
+    """> 1023 hittable spheres switches to the 32-bit-index kernels (global attenuation stack)."""
+    sc = r1.create_grid_scene(w, h, gw, gh)
+    assert int((sc.arrays()["inv_radius"] != 0).sum()) == gw * gh + 4 > 1023
+    renderer.set_scene(sc)
+    p = r1.make_params(w, h, spp, 31337)
+    img, rays, samples = renderer.render_samples(p)
+    oimg, orays, osamples = r1o.render_frame(oracle_scene(sc), oparams(p), want_samples=True)
+    assert rays == orays
+    assert samples.tobytes() == osamples.tobytes()
+    assert img.tobytes() == oimg.tobytes()
+    ref = renderer.render_samples(r1.make_params(w, h, spp, 31337, variant=binding.VARIANT_REFERENCE))
+    assert ref[1] == rays and ref[2].tobytes() == samples.tobytes()
+
+
+def test_config5_shape_100k_spheres_runs_and_matches_oracle_on_a_crop(renderer):
+    """BASELINE config 5 (100 004 spheres, 1920x1080 aspect): a small frame through the 100 k
+    sweep; the oracle checks a sample of pixel-samples (its brute-force frame would take minutes)."""
+    w, h, spp = 96, 54, 2
+    sc = r1.create_grid_scene(w, h, 400, 250)
+    renderer.set_scene(sc)
+    p = r1.make_params(w, h, spp, 5)
+    img, rays, samples = renderer.render_samples(p)
+    sa = oracle_scene(sc)
+    rng = np.random.default_rng(0)
+    xs, ys, ss = rng.integers(0, w, 300), rng.integers(0, h, 300), rng.integers(0, spp, 300)
+    rgb, orays = r1o.trace_samples(sa, w, h, 5, xs, ys, ss)
+    got = samples[(ys * w + xs) * spp + ss]
+    assert (rays_of(got) == orays).all()
+    assert got[:, :3].tobytes() == rgb.tobytes()
+    assert int(rays_of(samples).sum()) == rays
