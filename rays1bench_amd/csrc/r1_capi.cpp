@@ -234,10 +234,13 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
         r1_set_error("r1_set_scene: %u hittable spheres; this build supports up to %u", na, R1_MAX_ACTIVE);
         return R1_ELIMIT;
     }
-    const uint32_t ns = (na + 15u) & ~15u; // the sweep evaluates two 8-sphere chunks per loop trip
+    // small scenes: two 8-sphere chunks per loop trip + one prefetch chunk; big scenes: whole LDS
+    // tiles + one prefetch tile
+    const bool big_scene = na > R1_MAX_ACTIVE_10BIT;
+    const uint32_t ns = big_scene ? ((na + R1_TILE_SPHERES - 1) / R1_TILE_SPHERES) * R1_TILE_SPHERES : ((na + 15u) & ~15u);
 
     // sweep table: pair layout + one chunk of prefetch padding (see r1_device.h)
-    const uint32_t ns_alloc = ns + 8;
+    const uint32_t ns_alloc = ns + (big_scene ? R1_TILE_SPHERES : 8);
     std::vector<float> sweep(4 * (size_t)ns_alloc), exact(4 * (size_t)(na ? na : 1)), shade(4 * (size_t)(na ? na : 1)),
         mat(4 * (size_t)(na ? na : 1));
     auto sweep_slot = [&](uint32_t a, int comp) -> float & { return sweep[8 * (size_t)(a >> 1) + 2 * comp + (a & 1)]; };

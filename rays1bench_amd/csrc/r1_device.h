@@ -12,6 +12,8 @@
 #define R1_CHUNK 256        // most samples a wave takes from the global queue per atomic
 #define R1_CHUNK_MIN 32      // fewest (end of the queue: guided self-scheduling)
 #define R1_SAMPLES_PER_LANE 48 // grid sizing: samples each lane should get (see enqueue_frame)
+#define R1_TILE_SPHERES 512    // big-scene sweep: spheres per LDS tile (8 KB in pair layout), two tiles in LDS
+#define R1_TILE_F4 (R1_TILE_SPHERES / 2 * 2) // float4 per tile: 2 per pair of spheres
 #define R1_MAX_ACTIVE_10BIT 1023
 #define R1_MAX_ACTIVE (1u << 21) // big-scene kernels: 26-bit pair indices, limit kept at 2 M spheres
 #define R1_STACK_ENTRIES 51
@@ -36,7 +38,7 @@ struct R1DeviceScene
     const float4 *shade;   // {inv_radius, albedo_r, albedo_g, albedo_b}
     const float4 *mat;     // {bit_cast<float>(type), param, 1/ref_idx, ((1-ref)/(1+ref))^2} (last two: dielectrics)
     uint32_t n_active;     // real entries
-    uint32_t n_sweep;      // padded to a multiple of 16 (the table holds 8 more for the prefetch)
+    uint32_t n_sweep;      // padded to a multiple of 16 (+8 prefetch); big scenes: of R1_TILE_SPHERES (+ one tile)
 };
 
 struct R1DeviceCamera

@@ -259,11 +259,12 @@ __device__ __forceinline__ void cooperative_exact(const R1DeviceScene &S, const 
 // ---- sweep, prefilter form -----------------------------------------------------------------
 // (formula and slack: see the comment block above)  Called by all 64 lanes; lanes with
 // alive == false never flag a candidate but help in the cooperative exact phase.
-template <bool STATS, typename IDX>
+template <bool STATS, typename IDX, bool BLOCK_SYNC>
 __device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const bool alive, const V3 o, const V3 d, float &t_max,
                                                 int &hit_index, IDX *cand /* [R1_CAND_CAP][R1_BLOCK] */,
                                                 IDX *pairs /* [R1_BLOCK/64][R1_PAIR_CAP] */,
-                                                unsigned long long *best /* [R1_BLOCK] */, const int tid, unsigned long long *wstat)
+                                                unsigned long long *best /* [R1_BLOCK] */, f4 *tile /* BLOCK_SYNC: [2][R1_TILE_F4] */,
+                                                const int tid, unsigned long long *wstat)
 {
     const int lane = tid & 63;
     IDX *wpairs = pairs + (tid >> 6) * R1_PAIR_CAP;
@@ -320,21 +321,62 @@ __device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const bo
             }                                                                                                          \
         }                                                                                                              \
     }
-    // two register sets (A, B) alternate: while one chunk is evaluated the next one loads
-    f16 a0 = tab[0], a1 = tab[1];
-    for (uint32_t ch = 0; ch < chunks; ch += 2)
+    if (!BLOCK_SYNC)
     {
-        // Scalar loads return out of order, so lgkmcnt can only be waited to 0: make set A land
-        // BEFORE set B is requested (the empty asm "uses" A, which places the wait here), then
-        // evaluate A with B in flight and no further wait.
-        asm volatile("" ::"s"(a0[0]), "s"(a1[0]));
-        const f16 b0 = tab[2 * ch + 2], b1 = tab[2 * ch + 3];
-        __builtin_amdgcn_sched_barrier(0);
-        R1_CHUNK_EVAL(a0, a1, ch)
-        asm volatile("" ::"s"(b0[0]), "s"(b1[0]));
-        a0 = tab[2 * ch + 4], a1 = tab[2 * ch + 5];
-        __builtin_amdgcn_sched_barrier(0);
-        R1_CHUNK_EVAL(b0, b1, ch + 1)
+        // two register sets (A, B) alternate: while one chunk is evaluated the next one loads
+        f16 a0 = tab[0], a1 = tab[1];
+        for (uint32_t ch = 0; ch < chunks; ch += 2)
+        {
+            // Scalar loads return out of order, so lgkmcnt can only be waited to 0: make set A land
+            // BEFORE set B is requested (the empty asm "uses" A, which places the wait here), then
+            // evaluate A with B in flight and no further wait.
+            asm volatile("" ::"s"(a0[0]), "s"(a1[0]));
+            const f16 b0 = tab[2 * ch + 2], b1 = tab[2 * ch + 3];
+            __builtin_amdgcn_sched_barrier(0);
+            R1_CHUNK_EVAL(a0, a1, ch)
+            asm volatile("" ::"s"(b0[0]), "s"(b1[0]));
+            a0 = tab[2 * ch + 4], a1 = tab[2 * ch + 5];
+            __builtin_amdgcn_sched_barrier(0);
+            R1_CHUNK_EVAL(b0, b1, ch + 1)
+        }
+    }
+    else
+    {
+        // Big scenes (BASELINE config 5: 100 k spheres = 3.2 MB of table).  The scalar cache
+        // sustains under 1 B/clk/CU on misses (measured: 100 k spheres ran at a quarter of the
+        // small-scene rate), so the table goes through the VECTOR memory path instead: the
+        // workgroup stages R1_TILE_SPHERES-sphere tiles into LDS with coalesced 16-byte loads
+        // (each byte fetched once per workgroup and shared by its 256 rays), double-buffered,
+        // one barrier per tile, and every wave reads the tile back with broadcast ds_read_b128.
+        // The whole workgroup runs the bounce loop in lock step (see the kernel).
+        const f4 *gsrc = (const f4 *)S.sweep;
+        const uint32_t n_tiles = S.n_sweep / R1_TILE_SPHERES;
+        f4 r0 = gsrc[tid], r1 = gsrc[R1_BLOCK + tid];
+        __syncthreads(); // every wave has left the previous sweep's last tile
+        tile[tid] = r0, tile[R1_BLOCK + tid] = r1;
+        __syncthreads();
+        for (uint32_t ti = 0; ti < n_tiles; ++ti)
+        {
+            const f4 *cur = tile + (ti & 1u) * R1_TILE_F4;
+            const f4 *nsrc = gsrc + (size_t)(ti + 1) * R1_TILE_F4; // the table carries one padding tile
+            r0 = nsrc[tid], r1 = nsrc[R1_BLOCK + tid];
+#pragma unroll 2
+            for (uint32_t cc = 0; cc < R1_TILE_SPHERES / 8; ++cc)
+            {
+                const f4 *q4 = cur + cc * 8;
+                const f4 x0 = q4[0], x1 = q4[1], x2 = q4[2], x3 = q4[3], x4 = q4[4], x5 = q4[5], x6 = q4[6], x7 = q4[7];
+                const f16 l0 = __builtin_shufflevector(__builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7),
+                                                       __builtin_shufflevector(x2, x3, 0, 1, 2, 3, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7, 8,
+                                                       9, 10, 11, 12, 13, 14, 15);
+                const f16 l1 = __builtin_shufflevector(__builtin_shufflevector(x4, x5, 0, 1, 2, 3, 4, 5, 6, 7),
+                                                       __builtin_shufflevector(x6, x7, 0, 1, 2, 3, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7, 8,
+                                                       9, 10, 11, 12, 13, 14, 15);
+                R1_CHUNK_EVAL(l0, l1, ti * (R1_TILE_SPHERES / 8) + cc)
+            }
+            f4 *nxt = tile + ((ti + 1u) & 1u) * R1_TILE_F4;
+            nxt[tid] = r0, nxt[R1_BLOCK + tid] = r1;
+            __syncthreads();
+        }
     }
 #undef R1_CHUNK_EVAL
 #undef R1_PAIR
@@ -463,6 +505,7 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
     __shared__ IDX s_pairs[(R1_BLOCK / 64) * R1_PAIR_CAP];
     const uint32_t gstride = gridDim.x * R1_BLOCK, gtid = blockIdx.x * R1_BLOCK + threadIdx.x;
     __shared__ unsigned long long s_best[R1_BLOCK];
+    __shared__ f4 s_tile[BIG ? 2 * R1_TILE_F4 : 1];
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
@@ -515,7 +558,13 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
             q_next += min((uint32_t)__popcll(need), avail);
             need = __ballot(!alive);
         }
-        if (__ballot(alive) == 0ull)
+        if (BIG)
+        {
+            // lock-step workgroup: leave together (every wave must reach the sweep's barriers)
+            if (!__syncthreads_or(alive ? 1 : 0))
+                break;
+        }
+        else if (__ballot(alive) == 0ull)
             break;
         // A frame's critical path is its longest bounce chain (up to 51 dependent sweeps, ~1/3 of
         // a 10-spp frame when the wave shares its SIMD with three others).  Waves that carry a
@@ -548,7 +597,7 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
                 sweep_reference(A.scene, p.o, p.d, t_hit, hit);
         }
         else
-            sweep_prefilter<STATS, IDX>(A.scene, alive, p.o, p.d, t_hit, hit, s_cand, s_pairs, s_best, tid, wstat);
+            sweep_prefilter<STATS, IDX, BIG>(A.scene, alive, p.o, p.d, t_hit, hit, s_cand, s_pairs, s_best, s_tile, tid, wstat);
         if (STATS)
         {
             wstat[6] += __builtin_readcyclecounter() - wstat[15];

@@ -275,3 +275,28 @@ def test_config5_shape_100k_spheres_runs_and_matches_oracle_on_a_crop(renderer):
     assert (rays_of(got) == orays).all()
     assert got[:, :3].tobytes() == rgb.tobytes()
     assert int(rays_of(samples).sum()) == rays
+
+
+# ---- the drop-in host program (C++: create_*_scene / benchmark / main -w -n) ---------------------
+
+
+def test_rayweek1_hip_program_matches_the_abi_path(renderer, tmp_path):
+    """rayweek1_hip prints the reference's report block, writes out_<scene>.txt / .tga in the
+    reference's formats, and its pixels equal what the C-ABI returns for the same parameters."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "rays1bench_amd", "lib", "rayweek1_hip")
+    w, h, spp = 160, 96, 3
+    out = subprocess.run([exe, "-w", "-n", "2", "--width", str(w), "--height", str(h), "--spp", str(spp)], cwd=tmp_path,
+                         capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()
+    text = out.stdout.decode()
+    for name in SCENES:
+        blocks = re.findall(rf"^{name}\nelapsed time:   \d+\.\d{{3}}s\ntotal samples:  (\d+)\ntotal rays:     (\d+)\nmrays/s:        \d+\.\d\d\n",
+                            text, flags=re.M)
+        assert len(blocks) == 2 and all(int(b[0]) == w * h * spp for b in blocks)
+        renderer.set_scene(MAKE[name](w, h))
+        img, rays, _ = renderer.render(r1.make_params(w, h, spp, 10001))
+        assert {int(b[1]) for b in blocks} == {rays}
+        assert open(tmp_path / f"out_{name}.tga", "rb").read() == r1o.tga_bytes(img)
+        assert re.fullmatch(rf"hip\|\d+\.\d{{3}}s\|{rays}\|\d+\.\d{{3}} mrays/s\|", open(tmp_path / f"out_{name}.txt").read())

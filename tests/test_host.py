@@ -131,3 +131,15 @@ def test_product_does_not_touch_the_oracle():
                 seen += 1
                 assert not bad.search(open(os.path.join(dp, fn)).read()), fn
     assert seen >= 7
+
+
+def test_rayweek1_hip_fails_loudly_without_gpu(tmp_path):
+    """The drop-in host program has no CPU path: without a HIP device it exits non-zero."""
+    import subprocess
+    if r1.device_count() > 0:
+        pytest.skip("a GPU is present")
+    exe = os.path.join(ROOT, "rays1bench_amd", "lib", "rayweek1_hip")
+    out = subprocess.run([exe, "--width", "32", "--height", "32", "--spp", "1"], cwd=tmp_path, capture_output=True, timeout=120)
+    assert out.returncode == 2
+    assert b"cannot create HIP context" in out.stderr
+    assert not os.path.exists(tmp_path / "out_large.txt")
