@@ -165,7 +165,8 @@ size_t r1_shard_block_bytes(const r1_params *params);
  *   d_block      r1_shard_block_bytes() bytes: tiles_per_shard tiles of tile_h*tile_w*3
  *                bytes each, local tile j = global tile shard + j*num_shards
  *   d_num_rays   one uint64 (overwritten)
- * Does not synchronise. */
+ * Does not synchronise.  Sized for throughput: meant to be called for several frames in
+ * flight (one context + stream per frame in flight). */
 int r1_render_shard_device(r1_context *ctx, const r1_params *params, void *d_block, void *d_num_rays, void *hip_stream);
 
 /* Scatters `num_shards` gathered blocks (concatenated in shard order, device memory)

@@ -342,7 +342,8 @@ static int prepare_tiles(r1_context *c, const r1_params *p)
 }
 
 // Enqueues trace + resolve on `st`. out/d_rays are device pointers.
-static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int block_layout, void *d_rays, hipStream_t st)
+static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int block_layout, void *d_rays, hipStream_t st,
+                         bool throughput_mode)
 {
     if (!c->have_scene)
     {
@@ -397,12 +398,15 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
         per_cu = 1;
     if (per_cu > 8)
         per_cu = 8;
-    // Persistent grid.  A wave's lanes run dry one by one at the end of its share (the longest
-    // bounce chain of 64 lanes is ~20 sweeps), so a wave needs many times that much work to stay
-    // full: give every lane >= R1_SAMPLES_PER_LANE samples and let concurrent frames (other
-    // streams) fill the CUs a small frame leaves free.
+    // Persistent grid.  Latency mode (the synchronous host entry points: one frame, the caller
+    // waits): as many waves as fit, every lane at least one sample.  Throughput mode (the
+    // device-resident entry point, frames in flight on several streams): a wave's lanes run dry
+    // one by one at the end of its share (the longest bounce chain of 64 lanes is ~20 sweeps), so
+    // a wave needs many times that much work to stay full — give every lane
+    // >= R1_SAMPLES_PER_LANE samples and let the other frames fill the CUs a small frame leaves.
     long long blocks = (long long)c->cus * per_cu;
-    static const long long spl = getenv("R1_SAMPLES_PER_LANE") ? atoll(getenv("R1_SAMPLES_PER_LANE")) : R1_SAMPLES_PER_LANE;
+    static const long long spl_env = getenv("R1_SAMPLES_PER_LANE") ? atoll(getenv("R1_SAMPLES_PER_LANE")) : R1_SAMPLES_PER_LANE;
+    const long long spl = throughput_mode ? (spl_env > 0 ? spl_env : 1) : 1;
     const long long needed = ((long long)c->total_samples + R1_BLOCK * spl - 1) / (R1_BLOCK * spl);
     if (blocks > needed)
         blocks = needed;
@@ -483,7 +487,7 @@ static int render_host(r1_context *c, const r1_params *p, uint8_t *rgb_out, uint
     if ((rc = ensure(c->counters, 512)))
         return rc;
     void *d_rays = (char *)c->counters.p + 32;
-    if ((rc = enqueue_frame(c, p, c->image.p, sharded ? 1 : 0, d_rays, c->stream)))
+    if ((rc = enqueue_frame(c, p, c->image.p, sharded ? 1 : 0, d_rays, c->stream, false)))
         return rc;
 
     uint64_t rays = 0;
@@ -566,7 +570,7 @@ extern "C" int r1_render_shard_device(r1_context *c, const r1_params *p, void *d
         return R1_EINVAL;
     }
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    return enqueue_frame(c, p, d_block, 1, d_num_rays, st);
+    return enqueue_frame(c, p, d_block, 1, d_num_rays, st, true);
 }
 
 extern "C" int r1_assemble_device(r1_context *c, const r1_params *p, const void *d_blocks, void *d_rgb, void *hip_stream)

@@ -9,8 +9,12 @@
 // (common.h:86-122), but rendering through librays1.so (include/rays1.h) on a MI355X.
 //
 // What the reference fixes at compile time (common.h:19-28) is a run-time option here:
-//     --width W --height H --spp S --seed N --device D --variant V
+//     --width W --height H --spp S --seed N --device D --devices N --variant V
 // Defaults are the reference's multi-threaded defaults: 1280x720, 250 spp.
+// --devices N splits the frame over N HIP devices inside this one process (one host thread
+// and one r1_context per device, tile t -> device t % N, each device writes its own tiles of
+// the caller's pixel buffer): the in-process twin of the reference's thread pool
+// (rayweek1.cpp:785-842).  The RCCL-gather variant (one process per GPU) is bench.py's.
 
 #include <stdint.h>
 #include <stdio.h>
@@ -18,6 +22,9 @@
 #include <string.h>
 
 #include <chrono>
+#include <string>
+#include <thread>
+#include <vector>
 
 #include "../../include/rays1.h"
 
@@ -44,7 +51,8 @@ static int g_max_bounces = 50;
 static uint32_t g_seed = 10001;
 static int g_device = 0;
 static int g_variant = R1_VARIANT_DEFAULT;
-static r1_context *g_ctx = nullptr;
+static int g_devices = 1;
+static std::vector<r1_context *> g_ctx; // one per device in use
 
 // ---- Scene ---------------------------------------------------------------------------------------
 
@@ -89,14 +97,44 @@ RESULT benchmark(Scene *scene, Pix *pixels, bool write_tga, const char *scene_na
     p.shard = 0, p.num_shards = 1;
     p.variant = g_variant;
 
+    // one host thread per device; with one device this is a plain call
+    const int nd = (int)g_ctx.size();
+    std::vector<int> rcs(nd, R1_OK);
+    std::vector<uint64_t> rays(nd, 0);
+    std::vector<double> dev_s(nd, 0.0);
+    std::vector<std::string> errs(nd);
+    auto worker = [&](int i) {
+        r1_params q = p;
+        q.shard = i, q.num_shards = nd;
+        int rc = r1_set_scene(g_ctx[i], scene->hitables, scene->camera);
+        if (rc == R1_OK)
+            rc = r1_render(g_ctx[i], &q, &pixels[0].r, &rays[i], &dev_s[i]);
+        rcs[i] = rc;
+        if (rc != R1_OK)
+            errs[i] = r1_last_error(); // thread-local in the library
+    };
+    std::vector<std::thread> th;
+    for (int i = 1; i < nd; ++i)
+        th.emplace_back(worker, i);
+    worker(0);
+    for (auto &t : th)
+        t.join();
     double device_seconds = 0;
-    int rc = r1_set_scene(g_ctx, scene->hitables, scene->camera);
-    if (rc == R1_OK)
-        rc = r1_render(g_ctx, &p, &pixels[0].r, &result.num_rays, &device_seconds);
+    int rc = R1_OK;
+    for (int i = 0; i < nd; ++i)
+    {
+        result.num_rays += rays[i]; // rayweek1.cpp:809-813
+        device_seconds = dev_s[i] > device_seconds ? dev_s[i] : device_seconds;
+        if (rcs[i] != R1_OK && rc == R1_OK)
+        {
+            rc = rcs[i];
+            fprintf(stderr, "%s: device %d: %s\n", scene_name, i, errs[i].c_str());
+        }
+    }
     if (rc != R1_OK)
     {
         // the reference has no error convention: report and return RESULT{0,0}
-        fprintf(stderr, "%s: render failed (%d): %s\n", scene_name, rc, r1_last_error());
+        fprintf(stderr, "%s: render failed (%d)\n", scene_name, rc);
         result.num_rays = 0;
         delete scene;
         return result;
@@ -105,7 +143,7 @@ RESULT benchmark(Scene *scene, Pix *pixels, bool write_tga, const char *scene_na
 
     r1_launch_info li;
     memset(&li, 0, sizeof(li));
-    r1_last_launch_info(g_ctx, &li);
+    r1_last_launch_info(g_ctx[0], &li);
     uint64_t total_samples = (uint64_t)g_screen_w * g_screen_h * g_spp;
 
     printf("%s\n", scene_name);
@@ -113,7 +151,8 @@ RESULT benchmark(Scene *scene, Pix *pixels, bool write_tga, const char *scene_na
     printf("total samples:  %llu\n", (unsigned long long)total_samples);
     printf("total rays:     %llu\n", (unsigned long long)result.num_rays);
     printf("mrays/s:        %0.2f\n", result.get_mrays_per_sec());
-    printf("device:         hip:%d %d CUs, %d workgroups x %d threads\n", g_device, li.compute_units, li.blocks, li.threads_per_block);
+    printf("devices:        %d (first hip:%d, %d CUs, %d workgroups x %d threads)\n", nd, g_device, li.compute_units, li.blocks,
+           li.threads_per_block);
     printf("device time:    %.3fms (%0.2f mrays/s)\n", device_seconds * 1e3, device_seconds ? result.num_rays / device_seconds / 1e6 : 0.0);
     printf("\n");
 
@@ -166,20 +205,29 @@ int main(int argc, const char *argv[])
             g_seed = (uint32_t)strtoul(argv[++i], 0, 0);
         else if (strcmp(argv[i], "--device") == 0 && i + 1 < argc)
             g_device = atoi(argv[++i]);
+        else if (strcmp(argv[i], "--devices") == 0 && i + 1 < argc)
+            g_devices = atoi(argv[++i]);
         else if (strcmp(argv[i], "--variant") == 0 && i + 1 < argc)
             g_variant = atoi(argv[++i]);
     }
-    if (g_screen_w <= 0 || g_screen_h <= 0 || g_spp <= 0)
+    if (g_screen_w <= 0 || g_screen_h <= 0 || g_spp <= 0 || g_devices < 1 || g_devices > 64)
     {
-        fprintf(stderr, "bad --width/--height/--spp\n");
+        fprintf(stderr, "bad --width/--height/--spp/--devices\n");
         return 1;
     }
 
-    // HIP context creation stays outside the timed region and is shared by all -n runs
-    if (r1_create(g_device, &g_ctx) != R1_OK)
+    // HIP context creation stays outside the timed region and is shared by all -n runs.
+    // Devices wrap around the visible ones, so --devices 2 also works (oversubscribed) on one GPU.
+    const int visible = r1_device_count();
+    for (int i = 0; i < g_devices; ++i)
     {
-        fprintf(stderr, "cannot create HIP context: %s\n", r1_last_error());
-        return 2;
+        r1_context *c = nullptr;
+        if (visible <= 0 || r1_create((g_device + i) % visible, &c) != R1_OK)
+        {
+            fprintf(stderr, "cannot create HIP context: %s\n", r1_last_error());
+            return 2;
+        }
+        g_ctx.push_back(c);
     }
 
     Pix *pixels = new Pix[(size_t)g_screen_w * g_screen_h];
@@ -200,6 +248,7 @@ int main(int argc, const char *argv[])
     log_results(version, "large", results, num_runs);
 
     delete[] pixels;
-    r1_destroy(g_ctx);
+    for (r1_context *c : g_ctx)
+        r1_destroy(c);
     return 0;
 }

@@ -300,3 +300,52 @@ def test_rayweek1_hip_program_matches_the_abi_path(renderer, tmp_path):
         assert {int(b[1]) for b in blocks} == {rays}
         assert open(tmp_path / f"out_{name}.tga", "rb").read() == r1o.tga_bytes(img)
         assert re.fullmatch(rf"hip\|\d+\.\d{{3}}s\|{rays}\|\d+\.\d{{3}} mrays/s\|", open(tmp_path / f"out_{name}.txt").read())
+    # --devices 3: three contexts / host threads, each writing its own tiles (wraps onto the one GPU here)
+    single = {n: open(tmp_path / f"out_{n}.tga", "rb").read() for n in SCENES}
+    out3 = subprocess.run([exe, "-w", "--devices", "3", "--width", str(w), "--height", str(h), "--spp", str(spp)], cwd=tmp_path,
+                          capture_output=True, timeout=300)
+    assert out3.returncode == 0, out3.stderr.decode()
+    assert "devices:        3" in out3.stdout.decode()
+    for n in SCENES:
+        assert open(tmp_path / f"out_{n}.tga", "rb").read() == single[n]
+    rays1 = re.findall(r"total rays:     (\d+)", text)[::2]
+    assert re.findall(r"total rays:     (\d+)", out3.stdout.decode()) == rays1
+
+
+# ---- tiling is a pure work split: the image does not depend on it -----------------------------------
+
+
+@pytest.mark.parametrize("tile_w,tile_h", [(32, 32), (16, 16), (64, 8), (24, 40), (7, 5), (128, 128)])
+def test_image_is_independent_of_tile_size_and_matches_oracle(renderer, tile_w, tile_h):
+    w, h, spp = 150, 90, 3
+    sc = r1.create_medium_scene(w, h)
+    renderer.set_scene(sc)
+    p = r1.make_params(w, h, spp, 42, tile_w=tile_w, tile_h=tile_h)
+    img, rays, samples = renderer.render_samples(p)
+    oimg, orays, osamples = r1o.render_frame(oracle_scene(sc), oparams(r1.make_params(w, h, spp, 42)), want_samples=True)
+    assert rays == orays
+    assert samples.tobytes() == osamples.tobytes()
+    assert img.tobytes() == oimg.tobytes()
+    # and any shard count reassembles the same frame with that tile size
+    acc = np.zeros_like(img)
+    total = 0
+    for s in range(3):
+        part = np.zeros_like(img)
+        total += renderer.render_into(r1.make_params(w, h, spp, 42, tile_w=tile_w, tile_h=tile_h, shard=s, num_shards=3), part)[0]
+        acc = np.maximum(acc, part)
+    assert total == rays and acc.tobytes() == img.tobytes()
+
+
+def test_bad_arguments_are_rejected_not_rendered(renderer):
+    renderer.set_scene(r1.create_small_scene(64, 64))
+    for bad in (dict(width=0), dict(spp=0), dict(max_bounces=0), dict(max_bounces=52), dict(tile_w=0), dict(shard=2, num_shards=2),
+                dict(num_shards=0)):
+        kw = dict(width=64, height=64, spp=1, seed=1, max_bounces=50, tile_w=32, tile_h=32, shard=0, num_shards=1)
+        kw.update(bad)
+        with pytest.raises(r1.R1Error) as e:
+            renderer.render(r1.make_params(**kw))
+        assert e.value.code == binding.R1_EINVAL, bad
+    fresh = r1.Renderer(0)
+    with pytest.raises(r1.R1Error):
+        fresh.render(r1.make_params(8, 8, 1))  # no scene set
+    fresh.close()
