@@ -234,10 +234,10 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
         r1_set_error("r1_set_scene: %u hittable spheres; this build supports up to %u", na, R1_MAX_ACTIVE);
         return R1_ELIMIT;
     }
-    // small scenes: two 8-sphere chunks per loop trip + one prefetch chunk; big scenes: whole LDS
+    // small scenes: whole 8-sphere chunks + one prefetch chunk; big scenes: whole LDS
     // tiles + one prefetch tile
     const bool big_scene = na > R1_MAX_ACTIVE_10BIT;
-    const uint32_t ns = big_scene ? ((na + R1_TILE_SPHERES - 1) / R1_TILE_SPHERES) * R1_TILE_SPHERES : ((na + 15u) & ~15u);
+    const uint32_t ns = big_scene ? ((na + R1_TILE_SPHERES - 1) / R1_TILE_SPHERES) * R1_TILE_SPHERES : ((na + 7u) & ~7u);
 
     // sweep table: pair layout + one chunk of prefetch padding (see r1_device.h)
     const uint32_t ns_alloc = ns + (big_scene ? R1_TILE_SPHERES : 8);

@@ -30,7 +30,7 @@ struct R1DeviceScene
 {
     // Prefilter table over the ACTIVE spheres (inv_radius != 0), 8 floats per PAIR of spheres
     // {cx0 cx1 cy0 cy1 cz0 cz1 Kp0 Kp1}, Kp = |c|^2 - r^2 - slack; padded with never-candidate
-    // entries (Kp = +inf) to a multiple of 16 spheres PLUS one extra chunk of 8 (prefetch target).
+    // entries (Kp = +inf) to a multiple of 8 spheres PLUS one extra chunk of 8 (prefetch target).
     const float4 *sweep;
     // Exact table, same indexing: {cx, cy, cz, radius_sq} and {inv_radius, albedo rgb},
     // {type, param}.
@@ -38,7 +38,7 @@ struct R1DeviceScene
     const float4 *shade;   // {inv_radius, albedo_r, albedo_g, albedo_b}
     const float4 *mat;     // {bit_cast<float>(type), param, 1/ref_idx, ((1-ref)/(1+ref))^2} (last two: dielectrics)
     uint32_t n_active;     // real entries
-    uint32_t n_sweep;      // padded to a multiple of 16 (+8 prefetch); big scenes: of R1_TILE_SPHERES (+ one tile)
+    uint32_t n_sweep;      // padded to a multiple of 8 (+8 prefetch); big scenes: of R1_TILE_SPHERES (+ one tile)
 };
 
 struct R1DeviceCamera

@@ -289,7 +289,7 @@ __device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const bo
     const v2f mxx = {mx, mx}, myy = {my, my}, mzz = {mz, mz};
     const v2f nod = {negod, negod}, ooa = {oo_adj, oo_adj};
     const cf16_ptr tab = (cf16_ptr)S.sweep;
-    const uint32_t chunks = S.n_sweep >> 3; // even (r1_capi.cpp pads to 16 spheres + one prefetch chunk)
+    const uint32_t chunks = S.n_sweep >> 3; // r1_capi.cpp pads to 8 spheres + one prefetch chunk
 
 #define R1_PAIR(P, L, B)                                                                                               \
     {                                                                                                                  \
@@ -325,7 +325,8 @@ __device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const bo
     {
         // two register sets (A, B) alternate: while one chunk is evaluated the next one loads
         f16 a0 = tab[0], a1 = tab[1];
-        for (uint32_t ch = 0; ch < chunks; ch += 2)
+        uint32_t ch = 0;
+        for (; ch + 1 < chunks; ch += 2)
         {
             // Scalar loads return out of order, so lgkmcnt can only be waited to 0: make set A land
             // BEFORE set B is requested (the empty asm "uses" A, which places the wait here), then
@@ -339,6 +340,8 @@ __device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const bo
             __builtin_amdgcn_sched_barrier(0);
             R1_CHUNK_EVAL(b0, b1, ch + 1)
         }
+        if (ch < chunks) // odd number of chunks: the last one is already in set A
+            R1_CHUNK_EVAL(a0, a1, ch)
     }
     else
     {
