@@ -118,7 +118,10 @@ def main():
     if n > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=n, device_id=torch.device("cuda", local_rank))
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=n, device_id=torch.device("cuda", local_rank))
+        except TypeError:  # older torch: no device_id keyword
+            dist.init_process_group("nccl", rank=rank, world_size=n)
 
     w, h, spp = args.width, args.height, args.spp
     dev = torch.device("cuda", local_rank)
