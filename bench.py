@@ -92,6 +92,9 @@ def main():
                          "the CUs that a frame's last long bounce chains leave idle (1 = one frame at a time)")
     ap.add_argument("--emulate-shards", type=int, default=0,
                     help="tuning aid: render only shard 0 of K on one GPU, no collective (per-rank load of a K-GPU run)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--check", action="store_true",
+                    help="after the timed region compare the gathered + assembled image and ray count with an unsharded render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -113,15 +116,20 @@ def main():
         n = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product has no CPU fallback)")
+    if os.environ.get("R1_BENCH_DEVICE"):  # rehearsal: several ranks on one GPU (gloo backend)
+        local_rank = int(os.environ["R1_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dist = None
     if n > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        try:
-            dist.init_process_group("nccl", rank=rank, world_size=n, device_id=torch.device("cuda", local_rank))
-        except TypeError:  # older torch: no device_id keyword
-            dist.init_process_group("nccl", rank=rank, world_size=n)
+        if args.backend != "nccl":
+            dist.init_process_group(args.backend, rank=rank, world_size=n)
+        else:
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=n, device_id=torch.device("cuda", local_rank))
+            except TypeError:  # older torch: no device_id keyword
+                dist.init_process_group("nccl", rank=rank, world_size=n)
 
     w, h, spp = args.width, args.height, args.spp
     dev = torch.device("cuda", local_rank)
@@ -200,6 +208,16 @@ def main():
     torch.cuda.synchronize()
     local_rays = int(slots[0].rays.item())
 
+    check = None
+    if args.check:
+        import numpy as np
+        torch.cuda.synchronize()
+        got = slots[0].image.cpu().numpy()
+        got_rays = rays_per_step
+        ref = np.zeros((h, w, 3), np.uint8)
+        ref_rays, _ = rend.render_into(r1.make_params(w, h, spp, args.seed, variant=args.variant), ref)
+        check = bool(got.tobytes() == ref.tobytes() and got_rays == ref_rays)
+
     if rank == 0:
         n_pad = info["spheres_padded"]
         kernel_s = trace_ms_sum / max(frames, 1) * 1e-3
@@ -241,6 +259,8 @@ def main():
                                   "note": "16 flop per ray-sphere test as the reference counts them (SURVEY.md §8d); aggregate over "
                                           "the timed region (all launches / elapsed); one isolated launch (--inflight 1): DESIGN.md §7"}},
         }
+        if check is not None:
+            out["check"] = check
         if n == 1:
             # PCIe-inclusive: the host-returning entry point (pixels + count copied back every frame)
             import numpy as np

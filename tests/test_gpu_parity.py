@@ -349,3 +349,28 @@ def test_bad_arguments_are_rejected_not_rendered(renderer):
     with pytest.raises(r1.R1Error):
         fresh.render(r1.make_params(8, 8, 1))  # no scene set
     fresh.close()
+
+
+# ---- bench.py's N > 1 path, rehearsed on one GPU -------------------------------------------------
+
+
+def test_bench_two_ranks_rehearsal_gathers_the_unsharded_frame():
+    """Two bench.py ranks share the one GPU (R1_BENCH_DEVICE=0) with gloo standing in for RCCL:
+    real kernels, real tile split, the same gather_blocks/assemble code as the N-GPU run.
+    --check compares the gathered + assembled image and ray count with an unsharded render."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, R1_BENCH_DEVICE="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "--steps", "6", "--warmup", "2", "--inflight", "4", "--check", "--width", "300", "--height", "200", "--spp", "4"],
+                         capture_output=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    assert line["check"] is True and line["n_gpus"] == 2 and line["scaling"] == "strong"
+    assert "cpu_baseline" not in line and line["roofline"]["bound"] == "hbm"
