@@ -53,6 +53,8 @@ static int g_device = 0;
 static int g_variant = R1_VARIANT_DEFAULT;
 static int g_devices = 1;
 static std::vector<r1_context *> g_ctx; // one per device in use
+static std::vector<double> g_device_seconds; // per benchmark() call, for the JSON record
+static r1_launch_info g_last_info;
 
 // ---- Scene ---------------------------------------------------------------------------------------
 
@@ -144,6 +146,8 @@ RESULT benchmark(Scene *scene, Pix *pixels, bool write_tga, const char *scene_na
     r1_launch_info li;
     memset(&li, 0, sizeof(li));
     r1_last_launch_info(g_ctx[0], &li);
+    g_last_info = li;
+    g_device_seconds.push_back(device_seconds);
     uint64_t total_samples = (uint64_t)g_screen_w * g_screen_h * g_spp;
 
     printf("%s\n", scene_name);
@@ -174,6 +178,36 @@ static void log_results(const char *version, const char *scene, const RESULT *re
     for (int i = 0; i < num_runs; ++i)
         el[i] = results[i].elapsed_seconds, rays[i] = results[i].num_rays;
     r1_log_results(version, scene, el, rays, num_runs);
+}
+
+// next to the reference's out_<scene>.txt (parsed by update_readme.py) a JSON
+// record with what the HIP backend can add: device count, per-run device time, and the
+// roofline fractions in the survey's accounting (16 B and 16 flop per ray-sphere test).
+static void log_json(const char *version, const char *scene, const RESULT *results, int num_runs)
+{
+    char filename[128];
+    snprintf(filename, sizeof(filename), "out_%s.json", scene);
+    FILE *f = fopen(filename, "wt");
+    if (!f || g_device_seconds.size() < (size_t)num_runs)
+        return;
+    double el = 0, dev = 0;
+    uint64_t rays = 0;
+    const size_t first = g_device_seconds.size() - (size_t)num_runs;
+    fprintf(f, "{\"version\": \"%s\", \"scene\": \"%s\", \"width\": %d, \"height\": %d, \"spp\": %d, \"devices\": %d,\n \"runs\": [", version, scene,
+            g_screen_w, g_screen_h, g_spp, (int)g_ctx.size());
+    for (int i = 0; i < num_runs; ++i)
+    {
+        fprintf(f, "%s{\"elapsed_seconds\": %.6f, \"num_rays\": %llu, \"device_seconds\": %.6f}", i ? ", " : "", results[i].elapsed_seconds,
+                (unsigned long long)results[i].num_rays, g_device_seconds[first + i]);
+        el += results[i].elapsed_seconds, dev += g_device_seconds[first + i], rays += results[i].num_rays;
+    }
+    const double per_ray = 16.0 * g_last_info.spheres_padded; // bytes == flop per ray in the survey's model
+    const double rays_per_dev_s = dev > 0 ? rays / dev : 0;
+    fprintf(f, "],\n \"mrays_per_s\": %.3f, \"device_mrays_per_s\": %.3f, \"spheres_padded\": %d, \"spheres_active\": %d,\n", el > 0 ? rays / el / 1e6 : 0.0,
+            rays_per_dev_s / 1e6, g_last_info.spheres_padded, g_last_info.spheres_active);
+    fprintf(f, " \"algorithmic_bytes_per_ray\": %.0f, \"hbm_algorithmic_fraction_of_8TBs\": %.4f, \"fp32_vector_fraction_of_157TFs\": %.4f}\n", per_ray,
+            rays_per_dev_s * per_ray / 8.0e12 / (double)g_ctx.size(), rays_per_dev_s * per_ray / 157.3e12 / (double)g_ctx.size());
+    fclose(f);
 }
 
 int main(int argc, const char *argv[])
@@ -238,14 +272,17 @@ int main(int argc, const char *argv[])
     for (int i = 0; i < num_runs; ++i)
         results[i] = benchmark(create_small_scene(), pixels, write_tga, "small");
     log_results(version, "small", results, num_runs);
+    log_json(version, "small", results, num_runs);
 
     for (int i = 0; i < num_runs; ++i)
         results[i] = benchmark(create_medium_scene(), pixels, write_tga, "medium");
     log_results(version, "medium", results, num_runs);
+    log_json(version, "medium", results, num_runs);
 
     for (int i = 0; i < num_runs; ++i)
         results[i] = benchmark(create_large_scene(), pixels, write_tga, "large");
     log_results(version, "large", results, num_runs);
+    log_json(version, "large", results, num_runs);
 
     delete[] pixels;
     for (r1_context *c : g_ctx)

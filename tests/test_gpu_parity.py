@@ -300,6 +300,9 @@ def test_rayweek1_hip_program_matches_the_abi_path(renderer, tmp_path):
         assert {int(b[1]) for b in blocks} == {rays}
         assert open(tmp_path / f"out_{name}.tga", "rb").read() == r1o.tga_bytes(img)
         assert re.fullmatch(rf"hip\|\d+\.\d{{3}}s\|{rays}\|\d+\.\d{{3}} mrays/s\|", open(tmp_path / f"out_{name}.txt").read())
+        rec = json.load(open(tmp_path / f"out_{name}.json"))
+        assert rec["scene"] == name and rec["devices"] == 1 and len(rec["runs"]) == 2 and rec["runs"][0]["num_rays"] == rays
+        assert rec["algorithmic_bytes_per_ray"] == 16 * rec["spheres_padded"] and rec["fp32_vector_fraction_of_157TFs"] > 0
     # --devices 3: three contexts / host threads, each writing its own tiles (wraps onto the one GPU here)
     single = {n: open(tmp_path / f"out_{n}.tga", "rb").read() for n in SCENES}
     out3 = subprocess.run([exe, "-w", "--devices", "3", "--width", str(w), "--height", str(h), "--spp", str(spp)], cwd=tmp_path,
