@@ -9,16 +9,19 @@
 //   Lambertian/Metal/Dielectric::scatter   rayweek1.cpp:403-409 / :427-433 / :470-511
 //   TileRenderScheduler (atomic tile pop)  rayweek1.cpp:785-842   -> persistent waves + global sample queue
 //
-// Design (DESIGN.md has the long form):
-//   * one LANE per live path; a wave keeps all 64 lanes busy by refilling finished lanes
-//     from a global sample queue (chunks of R1_CHUNK samples per atomic), so the bounce-count
-//     divergence of color() (1..51 rays per sample) costs no lanes;
-//   * the sphere table is wave-uniform: it is read with SCALAR loads (s_load_dwordx4..x16
-//     into SGPRs) and fed to the VALU as SGPR operands — no LDS round trip, no VGPRs;
-//   * pass 1 is an 8-instruction conservative prefilter (7 FMA + 1 compare per ray-sphere
-//     test, vs 11 in the reference's form); candidates are re-tested afterwards in the
-//     reference's exact arithmetic, lane-parallel, from a per-lane LDS list, so results are
-//     bit-identical to the reference's candidate rule (sign bit of its discriminant);
+// Design (DESIGN.md §4 has the long form and the measurements):
+//   * one LANE per live path; a wave keeps its 64 lanes busy by refilling finished lanes from a
+//     global sample queue (guided chunks of R1_CHUNK_MIN..R1_CHUNK samples per atomic), so the
+//     bounce-count divergence of color() (1..51 rays per sample) costs no lanes;
+//   * the sphere table is wave-uniform: it is read with SCALAR loads (two alternating sets of
+//     s_load_dwordx16) and fed to the VALU as SGPR-pair operands of v_pk_fma_f32 — two spheres
+//     per instruction, no LDS round trip, no VGPRs.  (Scenes above 1023 spheres stream the table
+//     through LDS tiles instead: the scalar cache cannot sustain a 3 MB stream.);
+//   * pass 1 is a conservative prefilter, 7 FMA + 1 compare per ray-sphere test (11 in the
+//     reference's form) = 4.5 VALU instructions per sphere per 64 rays; flagged (ray, sphere)
+//     pairs of the whole wave are compacted in LDS and re-tested 64 at a time in the reference's
+//     exact arithmetic, so results are bit-identical to the reference's candidate rule (sign bit
+//     of its discriminant) and closest-hit rule (strict compares, lowest index on ties);
 //   * attenuation is applied in the reference's right-nested order a0*(a1*(...*sky)) by
 //     keeping the hit indices of a path in a packed per-lane LDS stack;
 //   * per-sample radiance goes to HBM (16 B/sample) and a second kernel sums the samples of
