@@ -7,8 +7,8 @@
 
 A "step" is one full frame of the workload: every rank traces + resolves the tiles it owns
 (tile t -> rank t % N, include/rays1.h r1_params.shard), then the dense per-rank tile blocks
-are all-gathered with RCCL (torch.distributed "nccl"), the ray counts all-reduced and the
-row-major image assembled on every rank.  At N = 1 there is no collective.  The frame is
+(each with its 8-byte ray count appended) are all-gathered with RCCL (torch.distributed "nccl")
+— ONE collective per frame — and the row-major image is assembled on every rank.  At N = 1 there is no collective.  The frame is
 fixed (BASELINE: large scene, 1200x800x10 spp), so scaling is STRONG.  Inputs (sphere tables,
 camera) are resident in HBM before the timed region; the image stays in HBM (the
 PCIe-inclusive rate of the host-returning r1_render() is reported separately, never as
@@ -138,6 +138,9 @@ def main():
         p = r1.make_params(w, h, spp, args.seed, shard=0, num_shards=args.emulate_shards, variant=args.variant)
     block_bytes = binding.shard_block_bytes(p)
 
+    shards = max(n, args.emulate_shards, 1)
+    record_bytes = block_bytes + sharding.RECORD_TRAILER  # tile block + uint64 ray count: one all-gather per frame
+
     class Slot:
         """One frame in flight: its own context (stream-ordered workspace), buffers and stream."""
 
@@ -146,20 +149,24 @@ def main():
             gw, gh = (int(v) for v in args.grid.split("x")) if args.scene == "grid" else (0, 0)
             self.scene = r1.Scene(SCENE_KIND[args.scene], w, h, gw, gh)
             self.rend.set_scene(self.scene)
-            self.block = torch.zeros(block_bytes, dtype=torch.uint8, device=dev)
-            self.gathered = torch.zeros(max(n, args.emulate_shards) * block_bytes, dtype=torch.uint8, device=dev) \
-                if max(n, args.emulate_shards) > 1 else self.block
-            self.rays = torch.zeros(1, dtype=torch.int64, device=dev)
+            self.record = torch.zeros(record_bytes, dtype=torch.uint8, device=dev)
+            self.gathered = torch.zeros(shards * record_bytes, dtype=torch.uint8, device=dev) if shards > 1 else self.record
             self.image = torch.zeros((h, w, 3), dtype=torch.uint8, device=dev)
             self.stream = torch.cuda.Stream(device=dev)
 
         def step(self):
             with torch.cuda.stream(self.stream):
                 sp = self.stream.cuda_stream
-                self.rend.render_shard_device(p, self.block.data_ptr(), self.rays.data_ptr(), sp)
+                self.rend.render_shard_device(p, self.record.data_ptr(), self.record.data_ptr() + block_bytes, sp)
                 if n > 1:
-                    sharding.gather_blocks(dist, self.block, self.gathered, self.rays)
-                self.rend.assemble_device(p, self.gathered.data_ptr(), self.image.data_ptr(), sp)
+                    sharding.gather_records(dist, self.record, self.gathered)
+                self.rend.assemble_device_strided(p, self.gathered.data_ptr(), record_bytes, self.image.data_ptr(), sp)
+
+        def local_rays(self):
+            return int(self.record[block_bytes:].view(torch.int64).item())
+
+        def frame_rays(self):
+            return sharding.total_rays(self.gathered, shards) if n > 1 else self.local_rays()
 
     slots = [Slot() for _ in range(max(1, args.inflight))]
     rend = slots[0].rend
@@ -180,7 +187,7 @@ def main():
     fence()
     slots[0].step()
     torch.cuda.synchronize()
-    rays_per_step = int(slots[0].rays.item())  # whole frame (all ranks) after the all-reduce
+    rays_per_step = slots[0].frame_rays()  # whole frame: the sum of the gathered trailers
 
     for sl in slots:
         sl.rend.timing_begin(args.steps)
@@ -203,10 +210,7 @@ def main():
     info = rend.launch_info()
 
     # local rays of this rank for the roofline of ITS kernel launches
-    with torch.cuda.stream(slots[0].stream):
-        rend.render_shard_device(p, slots[0].block.data_ptr(), slots[0].rays.data_ptr(), slots[0].stream.cuda_stream)
-    torch.cuda.synchronize()
-    local_rays = int(slots[0].rays.item())
+    local_rays = slots[0].local_rays()
 
     check = None
     if args.check:
@@ -240,7 +244,7 @@ def main():
             "config": {"workload": f"{args.scene} scene ({info['spheres_active']} spheres, N_pad {n_pad}), {w}x{h}, {spp} spp, "
                                    f"max 50 bounces, seed {args.seed}",
                        "rays_per_step": rays_per_step, "tiles": "32x32, tile t -> rank t % N",
-                       "parallelism": f"tile-split x{n}" + (" + RCCL all-gather" if n > 1 else ""),
+                       "parallelism": f"tile-split x{n}" + (" + one RCCL all-gather per frame (pixels + ray counts)" if n > 1 else ""),
                        "workgroups": info["blocks"], "threads_per_workgroup": info["threads_per_block"],
                        "frames_in_flight": len(slots)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

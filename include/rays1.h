@@ -173,6 +173,12 @@ int r1_render_shard_device(r1_context *ctx, const r1_params *params, void *d_blo
  * into the row-major image d_rgb (width*height*3 bytes, device memory). */
 int r1_assemble_device(r1_context *ctx, const r1_params *params, const void *d_blocks, void *d_rgb, void *hip_stream);
 
+/* Same, for blocks that are `shard_stride_bytes` apart (>= r1_shard_block_bytes; 0 = tight):
+ * lets a caller append per-shard trailers (e.g. the 8-byte ray count) to the gathered records so
+ * that one all-gather moves pixels and counts together. */
+int r1_assemble_device_strided(r1_context *ctx, const r1_params *params, const void *d_blocks, size_t shard_stride_bytes,
+                               void *d_rgb, void *hip_stream);
+
 /* Blocks until the context's stream is idle. */
 int r1_sync(r1_context *ctx);
 

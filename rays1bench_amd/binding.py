@@ -82,6 +82,7 @@ SYMBOLS = [
     ("r1_shard_block_bytes", C.c_size_t, [C.POINTER(Params)]),
     ("r1_render_shard_device", C.c_int, [_ctx, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p]),
     ("r1_assemble_device", C.c_int, [_ctx, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("r1_assemble_device_strided", C.c_int, [_ctx, C.POINTER(Params), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     ("r1_sync", C.c_int, [_ctx]),
     ("r1_last_timing", C.c_int, [_ctx, _dblp, _dblp]),
     ("r1_timing_begin", C.c_int, [_ctx, C.c_int32]),
@@ -220,6 +221,10 @@ class Renderer:
     def assemble_device(self, params, d_blocks_ptr, d_rgb_ptr, stream_ptr=None):
         _check(lib().r1_assemble_device(self._c, C.byref(params), C.c_void_p(d_blocks_ptr), C.c_void_p(d_rgb_ptr),
                                         C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def assemble_device_strided(self, params, d_blocks_ptr, shard_stride_bytes, d_rgb_ptr, stream_ptr=None):
+        _check(lib().r1_assemble_device_strided(self._c, C.byref(params), C.c_void_p(d_blocks_ptr), shard_stride_bytes,
+                                                C.c_void_p(d_rgb_ptr), C.c_void_p(stream_ptr) if stream_ptr else None))
 
     def sync(self):
         _check(lib().r1_sync(self._c))

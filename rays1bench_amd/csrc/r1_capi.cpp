@@ -21,7 +21,7 @@
 extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int blocks, hipStream_t stream);
 extern "C" hipError_t r1_launch_resolve(const R1ResolveArgs *args, hipStream_t stream);
 extern "C" hipError_t r1_launch_assemble(const void *blocks, void *rgb, int width, int height, int tile_w, int tile_h, int tiles_x,
-                                         int tiles_total, int num_shards, int tiles_per_shard, hipStream_t stream);
+                                         int tiles_total, int num_shards, int tiles_per_shard, size_t shard_stride, hipStream_t stream);
 extern "C" hipError_t r1_trace_occupancy(int variant, int big, int *blocks_per_cu);
 extern "C" int r1_params_check(const r1_params *p); // r1_host.cpp
 
@@ -573,7 +573,8 @@ extern "C" int r1_render_shard_device(r1_context *c, const r1_params *p, void *d
     return enqueue_frame(c, p, d_block, 1, d_num_rays, st, true);
 }
 
-extern "C" int r1_assemble_device(r1_context *c, const r1_params *p, const void *d_blocks, void *d_rgb, void *hip_stream)
+extern "C" int r1_assemble_device_strided(r1_context *c, const r1_params *p, const void *d_blocks, size_t shard_stride_bytes, void *d_rgb,
+                                          void *hip_stream)
 {
     if (!c || !p || !d_blocks || !d_rgb)
     {
@@ -584,11 +585,25 @@ extern "C" int r1_assemble_device(r1_context *c, const r1_params *p, const void 
     int rc = r1_tile_count(p, &total, &per);
     if (rc)
         return rc;
+    const size_t tight = (size_t)per * p->tile_w * p->tile_h * 3;
+    if (shard_stride_bytes == 0)
+        shard_stride_bytes = tight;
+    if (shard_stride_bytes < tight)
+    {
+        r1_set_error("r1_assemble_device: shard stride %zu smaller than a shard block (%zu bytes)", shard_stride_bytes, tight);
+        return R1_EINVAL;
+    }
     R1_HIP(hipSetDevice(c->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     const int tiles_x = (p->width + p->tile_w - 1) / p->tile_w;
-    R1_HIP(r1_launch_assemble(d_blocks, d_rgb, p->width, p->height, p->tile_w, p->tile_h, tiles_x, total, p->num_shards, per, st));
+    R1_HIP(r1_launch_assemble(d_blocks, d_rgb, p->width, p->height, p->tile_w, p->tile_h, tiles_x, total, p->num_shards, per,
+                              shard_stride_bytes, st));
     return R1_OK;
+}
+
+extern "C" int r1_assemble_device(r1_context *c, const r1_params *p, const void *d_blocks, void *d_rgb, void *hip_stream)
+{
+    return r1_assemble_device_strided(c, p, d_blocks, 0, d_rgb, hip_stream);
 }
 
 extern "C" int r1_sync(r1_context *c)

@@ -798,7 +798,7 @@ __global__ void __launch_bounds__(256) r1_resolve_kernel(const R1ResolveArgs A)
 // Scatter gathered dense tile blocks (shard-major) into a row-major image.
 __global__ void __launch_bounds__(256)
     r1_assemble_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ rgb, int width, int height, int tile_w, int tile_h,
-                       int tiles_x, int tiles_total, int num_shards, int tiles_per_shard)
+                       int tiles_x, int tiles_total, int num_shards, int tiles_per_shard, size_t shard_stride)
 {
     const size_t n = (size_t)width * height;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -806,12 +806,13 @@ __global__ void __launch_bounds__(256)
         const int y = (int)(i / (size_t)width), x = (int)(i - (size_t)y * width);
         const int tile = (y / tile_h) * tiles_x + (x / tile_w);
         const int shard = tile % num_shards, lt = tile / num_shards;
-        const size_t src = (((size_t)shard * tiles_per_shard + lt) * tile_h * tile_w + (size_t)(y % tile_h) * tile_w + (x % tile_w)) * 3;
+        const size_t src = (size_t)shard * shard_stride + (((size_t)lt * tile_h + (size_t)(y % tile_h)) * tile_w + (x % tile_w)) * 3;
         rgb[3 * i + 0] = blocks[src + 0];
         rgb[3 * i + 1] = blocks[src + 1];
         rgb[3 * i + 2] = blocks[src + 2];
     }
     (void)tiles_total;
+    (void)tiles_per_shard;
 }
 
 // ---- launchers (called from r1_capi.cpp) -----------------------------------------------------
@@ -842,14 +843,14 @@ extern "C" hipError_t r1_launch_resolve(const R1ResolveArgs *args, hipStream_t s
 }
 
 extern "C" hipError_t r1_launch_assemble(const void *blocks, void *rgb, int width, int height, int tile_w, int tile_h, int tiles_x,
-                                         int tiles_total, int num_shards, int tiles_per_shard, hipStream_t stream)
+                                         int tiles_total, int num_shards, int tiles_per_shard, size_t shard_stride, hipStream_t stream)
 {
     const size_t n = (size_t)width * height;
     int grid = (int)((n + 255) / 256);
     if (grid > 8192)
         grid = 8192;
     hipLaunchKernelGGL(r1_assemble_kernel, dim3(grid), dim3(256), 0, stream, (const uint8_t *)blocks, (uint8_t *)rgb, width, height,
-                       tile_w, tile_h, tiles_x, tiles_total, num_shards, tiles_per_shard);
+                       tile_w, tile_h, tiles_x, tiles_total, num_shards, tiles_per_shard, shard_stride);
     return hipGetLastError();
 }
 

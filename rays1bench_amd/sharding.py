@@ -56,9 +56,37 @@ def assemble(blocks, width, height, num_shards, tile_w=32, tile_h=32):
     return out
 
 
-def gather_blocks(dist, block, gathered, rays):
-    """The one exchange step of a frame: all-gather the per-rank tile blocks (RCCL on the GPU
-    box, gloo in the CPU tests) and sum the ray counts (rayweek1.cpp:809-813 does the same over
-    threads).  `block`/`gathered`/`rays` are torch tensors on the rank's device."""
-    dist.all_gather_into_tensor(gathered, block)
-    dist.all_reduce(rays)
+RECORD_TRAILER = 8  # bytes appended to a shard block: its uint64 ray count
+
+
+def record_bytes(width, height, num_shards, tile_w=32, tile_h=32):
+    """One rank's gather record: the dense tile block followed by the 8-byte ray count."""
+    return block_bytes(width, height, num_shards, tile_w, tile_h) + RECORD_TRAILER
+
+
+def gather_records(dist, record, gathered):
+    """The one exchange step of a frame: ONE all-gather (RCCL on the GPU box, gloo in the CPU
+    tests) of every rank's record = tile block + ray count, so pixels and counts travel together
+    (the reference sums `out_num_rays` over threads after the join, rayweek1.cpp:809-813).
+    `record`/`gathered` are uint8 torch tensors on the rank's device."""
+    dist.all_gather_into_tensor(gathered, record)
+
+
+def make_record(block, rays):
+    """numpy: dense tile block (flat uint8) + ray count -> one gather record."""
+    return np.concatenate([np.asarray(block, np.uint8), np.array([rays], np.uint64).view(np.uint8)])
+
+
+def assemble_records(gathered, width, height, num_shards, tile_w=32, tile_h=32):
+    """Host mirror of r1_assemble_device_strided over gathered records; returns (image, total rays)."""
+    g = np.asarray(gathered, np.uint8).reshape(num_shards, -1)
+    blocks = g[:, :-RECORD_TRAILER].reshape(-1)
+    rays = int(np.ascontiguousarray(g[:, -RECORD_TRAILER:]).view(np.uint64).sum())
+    return assemble(blocks, width, height, num_shards, tile_w, tile_h), rays
+
+
+def total_rays(gathered, num_shards):
+    """Sum of the ray counts in the trailers of a gathered buffer (torch uint8 tensor)."""
+    import torch
+    rec = gathered.numel() // num_shards
+    return int(gathered.view(num_shards, rec)[:, rec - RECORD_TRAILER:].contiguous().view(torch.int64).sum().item())

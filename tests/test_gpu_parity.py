@@ -238,6 +238,20 @@ def test_device_resident_shard_and_assemble(renderer):
     assert out.cpu().numpy().tobytes() == full.tobytes()
     t_trace, t_total = renderer.last_timing()
     assert 0 < t_trace <= t_total
+    # records = block + 8-byte ray count, strided assembly (what bench.py gathers)
+    rec = nbytes + 8
+    records = torch.zeros((shards, rec), dtype=torch.uint8, device="cuda")
+    for s in range(shards):
+        p = r1.make_params(w, h, spp, 21, shard=s, num_shards=shards)
+        renderer.render_shard_device(p, records[s].data_ptr(), records[s].data_ptr() + nbytes, stream)
+    out2 = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+    renderer.assemble_device_strided(r1.make_params(w, h, spp, 21, shard=0, num_shards=shards), records.data_ptr(), rec, out2.data_ptr(), stream)
+    torch.cuda.synchronize()
+    from rays1bench_amd import sharding
+    assert out2.cpu().numpy().tobytes() == full.tobytes()
+    assert sharding.total_rays(records.view(-1), shards) == full_rays
+    img_h, rays_h = sharding.assemble_records(records.cpu().numpy(), w, h, shards)
+    assert img_h.tobytes() == full.tobytes() and rays_h == full_rays
 
 
 # ---- big scenes (BASELINE config 5 shape: the large generator scaled up) -------------------------

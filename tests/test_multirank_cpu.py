@@ -1,6 +1,7 @@
 """world_size-2 (and 3) gloo tests of the N > 1 path on CPU: the tile -> rank split, the dense
-block layout, the all-gather + all-reduce exchange step (rays1bench_amd.sharding.gather_blocks,
-the same function bench.py calls with RCCL) and the assembly.  The device kernels cannot run
+record layout (tile block + ray count), the one all-gather of a frame
+(rays1bench_amd.sharding.gather_records, the same function bench.py calls with RCCL) and the
+assembly.  The device kernels cannot run
 here, so each rank fills its block with the ORACLE's render of exactly its shard; the checker
 is the oracle's render of the whole frame."""
 import os
@@ -40,14 +41,13 @@ def _rank_main(rank, world, port, out_dir):
         p = r1.make_params(W, H, SPP, SEED, shard=rank, num_shards=world)
         nbytes = binding.shard_block_bytes(p)
         assert nbytes == sharding.block_bytes(W, H, world)
-        block = torch.from_numpy(sharding.pack_block(part, rank, world))
-        assert block.numel() == nbytes
-        gathered = torch.zeros(world * nbytes, dtype=torch.uint8)
-        rays = torch.tensor([part_rays], dtype=torch.int64)
-        sharding.gather_blocks(dist, block, gathered, rays)
-        img = sharding.assemble(gathered.numpy(), W, H, world)
+        record = torch.from_numpy(sharding.make_record(sharding.pack_block(part, rank, world), part_rays))
+        assert record.numel() == nbytes + sharding.RECORD_TRAILER == sharding.record_bytes(W, H, world)
+        gathered = torch.zeros(world * record.numel(), dtype=torch.uint8)
+        sharding.gather_records(dist, record, gathered)  # the frame's one exchange step
+        img, rays = sharding.assemble_records(gathered.numpy(), W, H, world)
         full, full_rays, _ = r1o.render_frame(sa, r1o.make_params(W, H, SPP, SEED), nthreads=2)
-        assert int(rays.item()) == full_rays
+        assert rays == full_rays == sharding.total_rays(gathered, world)
         assert img.tobytes() == full.tobytes()
         # every pixel belongs to exactly one rank
         mine = np.zeros((H, W), np.int64)
