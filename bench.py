@@ -190,7 +190,7 @@ def main():
     rays_per_step = slots[0].frame_rays()  # whole frame: the sum of the gathered trailers
 
     for sl in slots:
-        sl.rend.timing_begin(args.steps)
+        sl.rend.timing_begin(args.steps // len(slots) + 2)  # frames this slot will carry
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
