@@ -391,3 +391,31 @@ def test_bench_two_ranks_rehearsal_gathers_the_unsharded_frame():
     line = json.loads(out.stdout.decode().strip().splitlines()[-1])
     assert line["check"] is True and line["n_gpus"] == 2 and line["scaling"] == "strong"
     assert "cpu_baseline" not in line and line["roofline"]["bound"] == "hbm"
+
+
+# ---- sphere-count edges: empty scene, last small-kernel scene, first big-kernel scene ------------
+
+
+@pytest.mark.parametrize("n_active", [0, 1, 7, 8, 9, 1023, 1024])
+def test_sphere_count_edges_vs_oracle(renderer, n_active):
+    w, h, spp = 64, 48, 2
+    src = r1.create_grid_scene(w, h, 36, 30)  # 1080 small spheres + ground + 3 big
+    arr = src.arrays()
+    keep = np.nonzero(arr["inv_radius"] != 0)[0][:n_active]
+    sub = {k: v[keep] for k, v in arr.items()}
+    # pad to a multiple of 8 with the reference's placeholders (rayweek1.cpp:574-576)
+    pad = (-len(keep)) % 8 or (8 if len(keep) == 0 else 0)
+    for k in sub:
+        fill = {"center_x": 999999999.0, "center_y": 999999999.0, "center_z": 999999999.0, "mat_type": 255}.get(k, 0)
+        sub[k] = np.concatenate([sub[k], np.full(pad, fill, sub[k].dtype)])
+    sa = r1o.SceneArrays(sub, src.camera_array())
+    renderer.set_scene_raw(_as_cscene(sa), _as_ccamera(sa))
+    p = r1.make_params(w, h, spp, 9)
+    img, rays, samples = renderer.render_samples(p)
+    assert renderer.launch_info()["spheres_active"] == n_active
+    oimg, orays, osamples = r1o.render_frame(sa, oparams(p), want_samples=True)
+    assert rays == orays
+    assert samples.tobytes() == osamples.tobytes()
+    assert img.tobytes() == oimg.tobytes()
+    if n_active == 0:
+        assert rays == w * h * spp  # every primary ray sees the sky
