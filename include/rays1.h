@@ -208,6 +208,7 @@ typedef struct r1_launch_info
     int32_t threads_per_block;
     int32_t spheres_active; /* spheres with inv_radius != 0 that the sweep visits */
     int32_t spheres_padded; /* `count` of the scene (N_pad of the reference)     */
+    int32_t groups;         /* sphere groups the first sweep level tests          */
     uint64_t samples;       /* pixel-samples traced                              */
 } r1_launch_info;
 int r1_last_launch_info(r1_context *ctx, r1_launch_info *out);

@@ -48,7 +48,7 @@ class Params(C.Structure):
 
 class LaunchInfo(C.Structure):
     _fields_ = [("compute_units", C.c_int32), ("blocks", C.c_int32), ("threads_per_block", C.c_int32),
-                ("spheres_active", C.c_int32), ("spheres_padded", C.c_int32), ("samples", C.c_uint64)]
+                ("spheres_active", C.c_int32), ("spheres_padded", C.c_int32), ("groups", C.c_int32), ("samples", C.c_uint64)]
 
 
 def make_params(width, height, spp, seed=10001, max_bounces=50, tile_w=32, tile_h=32, shard=0, num_shards=1, variant=0):

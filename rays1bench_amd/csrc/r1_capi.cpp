@@ -12,7 +12,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "../../include/rays1.h"
@@ -72,8 +74,8 @@ struct r1_context
     bool ring_on = false;
 
     // scene
-    DevBuf sweep, exact, shade, mat;
-    uint32_t n_active = 0, n_sweep = 0, n_padded_scene = 0;
+    DevBuf sweep, exact, shade, mat, members;
+    uint32_t n_active = 0, n_sweep = 0, n_padded_scene = 0, n_groups = 0;
     std::vector<uint32_t> active_to_scene;
     R1DeviceCamera cam;
     bool have_scene = false;
@@ -179,7 +181,7 @@ extern "C" void r1_destroy(r1_context *c)
     (void)hipSetDevice(c->device);
     if (c->stream)
         (void)hipStreamSynchronize(c->stream);
-    release(c->sweep), release(c->exact), release(c->shade), release(c->mat);
+    release(c->sweep), release(c->exact), release(c->shade), release(c->mat), release(c->members);
     release(c->gstack), release(c->counters), release(c->samples), release(c->image);
     for (hipEvent_t e : c->ring)
         (void)hipEventDestroy(e);
@@ -203,6 +205,129 @@ static float round_down(double v)
     if ((double)f > v)
         f = nextafterf(f, -INFINITY);
     return nextafterf(f, -INFINITY);
+}
+
+
+// ---- sphere groups (level 1 of the sweep) ------------------------------------------------------
+// The sweep tests GROUPS of up to R1_GROUP_MAX nearby spheres against a bounding sphere first and
+// re-tests the members of flagged groups exactly (r1_kernels.hip).  Grouping is a pure work
+// reduction: every active sphere belongs to exactly one group, the group test is conservative,
+// and hits are still resolved per sphere in the reference's arithmetic and index order.
+struct R1Group
+{
+    double gx, gy, gz, radius; // bounding sphere: |c_i - g| + r_i <= radius for every member
+    double c_max2;             // max(|g|^2, max_i |c_i|^2): magnitude that scales the fp32 error terms
+    uint32_t member[R1_GROUP_MAX];
+    int n;
+};
+
+static uint64_t spread21(uint64_t v) // 21 bits -> every third bit
+{
+    v &= 0x1FFFFF;
+    v = (v | v << 32) & 0x1F00000000FFFFull;
+    v = (v | v << 16) & 0x1F0000FF0000FFull;
+    v = (v | v << 8) & 0x100F00F00F00F00Full;
+    v = (v | v << 4) & 0x10C30C30C30C30C3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+}
+
+static void bound_of(const std::vector<uint32_t> &m, const std::vector<double> &x, const std::vector<double> &y,
+                     const std::vector<double> &z, const std::vector<double> &r, R1Group &g)
+{
+    // centre: middle of the members' axis-aligned extent (tight for the 2x2 blocks of a lattice)
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (uint32_t a : m)
+    {
+        const double c[3] = {x[a], y[a], z[a]};
+        for (int k = 0; k < 3; ++k)
+            lo[k] = fmin(lo[k], c[k] - r[a]), hi[k] = fmax(hi[k], c[k] + r[a]);
+    }
+    g.gx = 0.5 * (lo[0] + hi[0]), g.gy = 0.5 * (lo[1] + hi[1]), g.gz = 0.5 * (lo[2] + hi[2]);
+    g.radius = 0;
+    g.c_max2 = g.gx * g.gx + g.gy * g.gy + g.gz * g.gz;
+    for (uint32_t a : m)
+    {
+        const double dx = x[a] - g.gx, dy = y[a] - g.gy, dz = z[a] - g.gz;
+        g.radius = fmax(g.radius, sqrt(dx * dx + dy * dy + dz * dz) + r[a]);
+        g.c_max2 = fmax(g.c_max2, x[a] * x[a] + y[a] * y[a] + z[a] * z[a]);
+    }
+}
+
+static std::vector<R1Group> build_groups(uint32_t na, const std::vector<double> &x, const std::vector<double> &y,
+                                         const std::vector<double> &z, const std::vector<double> &r)
+{
+    static const long gmax_env = getenv("R1_GROUP_MAX") ? atol(getenv("R1_GROUP_MAX")) : R1_GROUP_MAX;
+    const int gmax = gmax_env < 1 ? 1 : (gmax_env > R1_GROUP_MAX ? R1_GROUP_MAX : (int)gmax_env);
+    std::vector<R1Group> groups;
+    auto close = [&](const std::vector<uint32_t> &m) {
+        R1Group g;
+        memset(&g, 0, sizeof(g));
+        bound_of(m, x, y, z, r, g);
+        g.n = (int)m.size();
+        for (int k = 0; k < R1_GROUP_MAX; ++k)
+            g.member[k] = k < g.n ? m[k] : 0xFFFFFFFFu;
+        groups.push_back(g);
+    };
+    if (na == 0)
+        return groups;
+    // spheres much larger than the typical one (the ground, the r = 2 balls) stay alone
+    std::vector<double> rs(r.begin(), r.begin() + na);
+    std::nth_element(rs.begin(), rs.begin() + na / 2, rs.end());
+    const double r_med = rs[na / 2];
+    std::vector<uint32_t> small;
+    for (uint32_t a = 0; a < na; ++a)
+        if (gmax > 1 && r[a] <= 2.5 * r_med)
+            small.push_back(a);
+        else
+            close(std::vector<uint32_t>(1, a));
+    if (small.empty())
+        return groups;
+    // Morton order of the centres, then greedy runs of <= gmax spheres whose bounding sphere
+    // stays within R1_GROUP_RATIO x the smallest member radius (keeps the bound selective and the
+    // slack analysis of DESIGN.md §4.1 valid)
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (uint32_t a : small)
+    {
+        lo[0] = fmin(lo[0], x[a]), hi[0] = fmax(hi[0], x[a]);
+        lo[1] = fmin(lo[1], y[a]), hi[1] = fmax(hi[1], y[a]);
+        lo[2] = fmin(lo[2], z[a]), hi[2] = fmax(hi[2], z[a]);
+    }
+    const double ext = fmax(fmax(hi[0] - lo[0], hi[1] - lo[1]), fmax(hi[2] - lo[2], 1e-30));
+    std::vector<std::pair<uint64_t, uint32_t>> keyed;
+    for (uint32_t a : small)
+    {
+        const uint64_t qx = (uint64_t)((x[a] - lo[0]) / ext * 2097151.0), qy = (uint64_t)((y[a] - lo[1]) / ext * 2097151.0),
+                       qz = (uint64_t)((z[a] - lo[2]) / ext * 2097151.0);
+        keyed.push_back({spread21(qx) | spread21(qy) << 1 | spread21(qz) << 2, a});
+    }
+    std::sort(keyed.begin(), keyed.end());
+    std::vector<uint32_t> cur;
+    for (auto &ka : keyed)
+    {
+        std::vector<uint32_t> tryg = cur;
+        tryg.push_back(ka.second);
+        bool ok = (int)tryg.size() <= gmax;
+        if (ok && tryg.size() > 1)
+        {
+            R1Group g;
+            bound_of(tryg, x, y, z, r, g);
+            double rmin = 1e300;
+            for (uint32_t a : tryg)
+                rmin = fmin(rmin, r[a]);
+            ok = g.radius <= R1_GROUP_RATIO * rmin;
+        }
+        if (ok)
+            cur = tryg;
+        else
+        {
+            close(cur);
+            cur.assign(1, ka.second);
+        }
+    }
+    if (!cur.empty())
+        close(cur);
+    return groups;
 }
 
 extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *cam)
@@ -234,26 +359,56 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
         r1_set_error("r1_set_scene: %u hittable spheres; this build supports up to %u", na, R1_MAX_ACTIVE);
         return R1_ELIMIT;
     }
-    // small scenes: whole 8-sphere chunks + one prefetch chunk; big scenes: whole LDS
-    // tiles + one prefetch tile
+    // level 1 of the sweep: groups of nearby spheres with a bounding sphere each
+    std::vector<double> ax(na ? na : 1), ay(na ? na : 1), az(na ? na : 1), ar_(na ? na : 1);
+    for (uint32_t a = 0; a < na; ++a)
+    {
+        const uint32_t i = c->active_to_scene[a];
+        ax[a] = s->center_x[i], ay[a] = s->center_y[i], az[a] = s->center_z[i];
+        ar_[a] = 1.0 / (double)s->inv_radius[i]; // inv_radius != 0 means radius > 0 (soa_sphere.cpp:81)
+    }
+    const std::vector<R1Group> groups = build_groups(na, ax, ay, az, ar_);
+    const uint32_t ng = (uint32_t)groups.size();
+
+    // small scenes: whole 8-group chunks + one prefetch chunk; big scenes: whole LDS tiles + one
+    // prefetch tile
     const bool big_scene = na > R1_MAX_ACTIVE_10BIT;
-    const uint32_t ns = big_scene ? ((na + R1_TILE_SPHERES - 1) / R1_TILE_SPHERES) * R1_TILE_SPHERES : ((na + 7u) & ~7u);
+    const uint32_t ns = big_scene ? ((ng + R1_TILE_SPHERES - 1) / R1_TILE_SPHERES) * R1_TILE_SPHERES : ((ng + 7u) & ~7u);
 
     // sweep table: pair layout + one chunk of prefetch padding (see r1_device.h)
     const uint32_t ns_alloc = ns + (big_scene ? R1_TILE_SPHERES : 8);
     std::vector<float> sweep(4 * (size_t)ns_alloc), exact(4 * (size_t)(na ? na : 1)), shade(4 * (size_t)(na ? na : 1)),
         mat(4 * (size_t)(na ? na : 1));
+    std::vector<uint32_t> members((size_t)R1_GROUP_MAX * ns_alloc, 0xFFFFFFFFu);
     auto sweep_slot = [&](uint32_t a, int comp) -> float & { return sweep[8 * (size_t)(a >> 1) + 2 * comp + (a & 1)]; };
     for (uint32_t a = 0; a < ns_alloc; ++a) // never-candidate default
         sweep_slot(a, 0) = sweep_slot(a, 1) = sweep_slot(a, 2) = 0, sweep_slot(a, 3) = INFINITY;
+    for (uint32_t g = 0; g < ng; ++g)
+    {
+        const R1Group &G = groups[g];
+        // the bounding sphere as fp32 centre + a radius that still covers the members after the
+        // centre is rounded to fp32
+        const float gx = (float)G.gx, gy = (float)G.gy, gz = (float)G.gz;
+        double R = 0;
+        for (int k = 0; k < G.n; ++k)
+        {
+            const uint32_t a = G.member[k];
+            const double dx = ax[a] - gx, dy = ay[a] - gy, dz = az[a] - gz;
+            R = fmax(R, sqrt(dx * dx + dy * dy + dz * dz) + ar_[a]);
+            members[(size_t)R1_GROUP_MAX * g + k] = a;
+        }
+        R *= 1.0 + 1e-12;
+        const double g2 = (double)gx * gx + (double)gy * gy + (double)gz * gz;
+        // Kp = (|g|^2 - R^2) - 2^-15 (C^2 + R^2), rounded down.  C^2 bounds |g|^2 and every
+        // member's |c|^2.  The slack covers the fp32 error of the group test itself AND of any
+        // member's reference test carried over to the bound: see sweep_prefilter.
+        const double kp = (g2 - R * R) - ldexp(fmax(G.c_max2, g2) + R * R, -15) - 1e-30;
+        sweep_slot(g, 0) = gx, sweep_slot(g, 1) = gy, sweep_slot(g, 2) = gz, sweep_slot(g, 3) = round_down(kp);
+    }
     for (uint32_t a = 0; a < na; ++a)
     {
         const uint32_t i = c->active_to_scene[a];
         const float cx = s->center_x[i], cy = s->center_y[i], cz = s->center_z[i], rsq = s->radius_sq[i];
-        const double c2 = (double)cx * cx + (double)cy * cy + (double)cz * cz;
-        // Kp = (|c|^2 - r^2) - 2^-17 (|c|^2 + r^2), rounded down: see sweep_prefilter
-        const double kp = (c2 - (double)rsq) - ldexp(c2 + (double)rsq, -17) - 1e-30;
-        sweep_slot(a, 0) = cx, sweep_slot(a, 1) = cy, sweep_slot(a, 2) = cz, sweep_slot(a, 3) = round_down(kp);
         exact[4 * a + 0] = cx, exact[4 * a + 1] = cy, exact[4 * a + 2] = cz, exact[4 * a + 3] = rsq;
         shade[4 * a + 0] = s->inv_radius[i], shade[4 * a + 1] = s->albedo_r[i], shade[4 * a + 2] = s->albedo_g[i],
                       shade[4 * a + 3] = s->albedo_b[i];
@@ -271,13 +426,16 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
 
     int rc;
     if ((rc = ensure(c->sweep, sweep.size() * 4)) || (rc = ensure(c->exact, exact.size() * 4)) ||
-        (rc = ensure(c->shade, shade.size() * 4)) || (rc = ensure(c->mat, mat.size() * 4)))
+        (rc = ensure(c->shade, shade.size() * 4)) || (rc = ensure(c->mat, mat.size() * 4)) ||
+        (rc = ensure(c->members, members.size() * 4)))
         return rc;
     R1_HIP(hipStreamSynchronize(c->stream));
     R1_HIP(hipMemcpy(c->sweep.p, sweep.data(), sweep.size() * 4, hipMemcpyHostToDevice));
     R1_HIP(hipMemcpy(c->exact.p, exact.data(), exact.size() * 4, hipMemcpyHostToDevice));
     R1_HIP(hipMemcpy(c->shade.p, shade.data(), shade.size() * 4, hipMemcpyHostToDevice));
     R1_HIP(hipMemcpy(c->mat.p, mat.data(), mat.size() * 4, hipMemcpyHostToDevice));
+    R1_HIP(hipMemcpy(c->members.p, members.data(), members.size() * 4, hipMemcpyHostToDevice));
+    c->n_groups = ng;
 
     c->n_active = na;
     c->n_sweep = ns;
@@ -368,6 +526,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     a.scene.exact = (const float4 *)c->exact.p;
     a.scene.shade = (const float4 *)c->shade.p;
     a.scene.mat = (const float4 *)c->mat.p;
+    a.scene.members = (const uint32_t *)c->members.p;
     a.scene.n_active = c->n_active;
     a.scene.n_sweep = c->n_sweep;
     a.cam = c->cam;
@@ -456,6 +615,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     c->info.threads_per_block = R1_BLOCK;
     c->info.spheres_active = (int32_t)c->n_active;
     c->info.spheres_padded = (int32_t)c->n_padded_scene;
+    c->info.groups = (int32_t)c->n_groups;
     c->info.samples = c->total_samples;
     return R1_OK;
 }

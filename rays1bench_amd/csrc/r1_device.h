@@ -11,6 +11,8 @@
 #define R1_STACK_WORDS 17   // ceil(51 / 3) packed 10-bit hit indices per lane (max_bounces <= 51)
 #define R1_CHUNK 256        // most samples a wave takes from the global queue per atomic
 #define R1_CHUNK_MIN 32      // fewest (end of the queue: guided self-scheduling)
+#define R1_GROUP_MAX 4         // spheres per group (level 1 of the sweep tests group bounds)
+#define R1_GROUP_RATIO 3.5     // a group's bounding radius stays within this factor of its smallest member radius
 #define R1_SAMPLES_PER_LANE 48 // grid sizing: samples each lane should get (see enqueue_frame)
 #define R1_TILE_SPHERES 512    // big-scene sweep: spheres per LDS tile (8 KB in pair layout), two tiles in LDS
 #define R1_TILE_F4 (R1_TILE_SPHERES / 2 * 2) // float4 per tile: 2 per pair of spheres
@@ -28,17 +30,19 @@ struct R1FastDiv
 // Everything the trace kernel needs; passed by value (kernarg segment => SGPRs).
 struct R1DeviceScene
 {
-    // Prefilter table over the ACTIVE spheres (inv_radius != 0), 8 floats per PAIR of spheres
-    // {cx0 cx1 cy0 cy1 cz0 cz1 Kp0 Kp1}, Kp = |c|^2 - r^2 - slack; padded with never-candidate
+    // Prefilter table over the GROUPS of active spheres (inv_radius != 0; <= R1_GROUP_MAX nearby
+    // spheres per group, bounding sphere (g, R)), 8 floats per PAIR of groups
+    // {gx0 gx1 gy0 gy1 gz0 gz1 Kp0 Kp1}, Kp = |g|^2 - R^2 - slack; padded with never-candidate
     // entries (Kp = +inf) to a multiple of 8 spheres PLUS one extra chunk of 8 (prefetch target).
     const float4 *sweep;
     // Exact table, same indexing: {cx, cy, cz, radius_sq} and {inv_radius, albedo rgb},
     // {type, param}.
     const float4 *exact;
     const float4 *shade;   // {inv_radius, albedo_r, albedo_g, albedo_b}
+    const uint32_t *members; // [n_sweep (+pad)][R1_GROUP_MAX] active indices of a group's spheres, 0xFFFFFFFF = none
     const float4 *mat;     // {bit_cast<float>(type), param, 1/ref_idx, ((1-ref)/(1+ref))^2} (last two: dielectrics)
     uint32_t n_active;     // real entries
-    uint32_t n_sweep;      // padded to a multiple of 8 (+8 prefetch); big scenes: of R1_TILE_SPHERES (+ one tile)
+    uint32_t n_sweep;      // GROUPS, padded to a multiple of 8 (+8 prefetch); big scenes: of R1_TILE_SPHERES (+ one tile)
 };
 
 struct R1DeviceCamera

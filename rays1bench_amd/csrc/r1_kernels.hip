@@ -177,12 +177,17 @@ __device__ __forceinline__ void sweep_reference(const R1DeviceScene &S, const V3
 // ---- sweep, prefilter form -----------------------------------------------------------------
 // For unit d:  discr = (co.d)^2 - |co|^2 + r^2  with co = c - o
 //            = (c.d - o.d)^2 - (|o|^2 - 2 c.o) - (|c|^2 - r^2)
-// Per ray:    negod = -(o.d), m2o = -2 o, oo' = |o|^2 (1 - 2^-17)
-// Per sphere: Kp = (|c|^2 - r^2) - 2^-17 (|c|^2 + r^2), rounded down          (host, r1_capi.cpp)
+// The test is applied to GROUPS of <= R1_GROUP_MAX nearby spheres through a bounding sphere
+// (g, R) that contains every member (host, r1_capi.cpp build_groups):
+// Per ray:    negod = -(o.d), m2o = -2 o, oo' = |o|^2 (1 - 2^-15)
+// Per group:  Kp = (|g|^2 - R^2) - 2^-15 (C^2 + R^2), rounded down, C^2 >= |g|^2 and every |c_i|^2
 // Test:       fma(nb', nb', -t') >= Kp   with two 3-FMA chains nb', t'        => 7 FMA + 1 compare
-// The slack 2^-17 (|c|^2 + r^2 + |o|^2) exceeds the worst-case fp32 error of BOTH this form and
-// the reference's form, so every sphere whose reference discriminant has a
-// clear sign bit is flagged here; exact_test then applies the reference's own rule.
+// If the REFERENCE flags member i (its fp32 discriminant has a clear sign bit), the ray's line
+// passes within sqrt(r_i^2 + E1) of c_i (E1 = the reference form's fp32 error), hence within
+// R + E1/(2 r_i) of g, i.e. the group's real-number discriminant is >= -R E1 / r_i; with
+// R <= 3.5 r_i (R1_GROUP_RATIO) and the error of this form itself that is > -2^-15 (C^2 + R^2 +
+// |o|^2), so the group is flagged here; cooperative_exact then applies the
+// reference's own rule to each member.
 // What ONE candidate sphere offers a ray, independent of the other candidates: pass 2 of
 // Hitable::hit (rayweek1.cpp:294-313) accepts t1 = nb - s when t1 > t_min, otherwise
 // t2 = nb + s when t2 > t_min, each only if it is below the running t_max; since t2 >= t1 a
@@ -237,19 +242,23 @@ __device__ __forceinline__ void cooperative_exact(const R1DeviceScene &S, const 
     for (int j = 0; j < cnt; ++j)
         pairs[excl + j] = (IDX)(((uint32_t)lane << IDX_BITS) | (uint32_t)cand[j * R1_BLOCK + tid]);
     __builtin_amdgcn_wave_barrier();
+    // Each flagged GROUP expands to its R1_GROUP_MAX member slots: 16 pairs x 4 members fill a
+    // trip; a lane takes pair (base + lane) / 4, member lane % 4.
+    const int slots = total * R1_GROUP_MAX;
     if (STATS)
-        wstat[2] += (unsigned long long)((total + 63) >> 6);
-    for (int base = 0; base < total; base += 64) // wave-uniform trip count
+        wstat[2] += (unsigned long long)((slots + 63) >> 6);
+    for (int base = 0; base < slots; base += 64) // wave-uniform trip count
     {
-        const int j = base + lane;
-        const bool have = j < total;
-        const uint32_t pr = have ? (uint32_t)pairs[j] : ((uint32_t)lane << IDX_BITS);
+        const int j = (base + lane) >> 2;
+        const bool have_pair = j < total;
+        const uint32_t pr = have_pair ? (uint32_t)pairs[j] : ((uint32_t)lane << IDX_BITS);
         const int owner = (int)(pr >> IDX_BITS);
-        const uint32_t idx = pr & ((1u << IDX_BITS) - 1u);
+        const uint32_t grp = pr & ((1u << IDX_BITS) - 1u);
+        const uint32_t idx = have_pair ? S.members[(size_t)grp * R1_GROUP_MAX + (lane & (R1_GROUP_MAX - 1))] : 0xFFFFFFFFu;
         V3 ro, rd;
         ro.x = __shfl(o.x, owner, 64), ro.y = __shfl(o.y, owner, 64), ro.z = __shfl(o.z, owner, 64);
         rd.x = __shfl(d.x, owner, 64), rd.y = __shfl(d.y, owner, 64), rd.z = __shfl(d.z, owner, 64);
-        if (have)
+        if (idx != 0xFFFFFFFFu)
         {
             const float t = exact_offer(((const f4 *)S.exact)[idx], ro, rd);
             if (t < FLT_MAX)
@@ -277,7 +286,7 @@ __device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const bo
     const float negod = -__fmaf_rn(o.z, d.z, __fmaf_rn(o.y, d.y, o.x * d.x));
     const float oo = __fmaf_rn(o.z, o.z, __fmaf_rn(o.y, o.y, o.x * o.x));
     // dead lanes: t' = +inf => q = -inf (or NaN) => never >= Kp
-    const float oo_adj = alive ? __fmaf_rn(oo, -0x1p-17f, oo) : __builtin_inff();
+    const float oo_adj = alive ? __fmaf_rn(oo, -0x1p-15f, oo) : __builtin_inff();
     const float mx = -2.0f * o.x, my = -2.0f * o.y, mz = -2.0f * o.z;
 
     wbest[lane] = NONE;
