@@ -214,36 +214,38 @@ __device__ __forceinline__ float exact_offer(const f4 e, const V3 o, const V3 d)
     return offer;
 }
 
-// Wave-cooperative exact phase.  Per-lane candidate counts are very uneven (mean 2.2, max of
-// 64 lanes ~8.5, a few rays skim a whole row of spheres), so the (ray, sphere) pairs of the
-// whole wave are compacted into one dense LDS list and re-tested 64 at a time by whichever
-// lane comes next: ~3 full-width trips instead of ~9 mostly-empty ones.  Offers are combined
-// per ray with a 64-bit LDS atomic min on {t bits, sphere index}: closest hit, ties to the
-// lowest index — the reference's rule.  Must be called by ALL 64 lanes (full EXEC).
-// IDX = uint16_t (<= 1023 active spheres: 6 lane bits + 10 index bits per pair) or uint32_t
-// (big scenes: 6 + 26 bits).
-template <bool STATS, typename IDX>
-__device__ __forceinline__ void cooperative_exact(const R1DeviceScene &S, const V3 o, const V3 d, int cnt, const IDX *cand,
-                                                  IDX *pairs /* this wave's [R1_PAIR_CAP] */, unsigned long long *best /* this wave's [64] */,
-                                                  const int tid, const int lane, unsigned long long *wstat)
+// Wave-cooperative exact phase.  Flag counts per lane are very uneven (mean ~3 groups, max of
+// 64 lanes ~10, a few rays skim a whole row of spheres), so the (ray, group) pairs of the whole
+// wave are compacted into one dense LDS list and re-tested 64 member slots at a time by
+// whichever lane comes next: full-width trips instead of mostly-empty ones.  Offers are
+// combined per ray with a 64-bit LDS atomic min on {t bits, sphere index}: closest hit, ties to
+// the lowest index — the reference's rule.  All of this must be called by ALL 64 lanes.
+// IDX = uint16_t (<= 1023 groups: 6 lane bits + 10 group bits per pair) or uint32_t (6 + 26).
+template <typename IDX>
+struct PairBits
 {
-    constexpr int IDX_BITS = sizeof(IDX) == 2 ? 10 : 26;
-    // exclusive prefix sum of cnt over the wave
-    int incl = cnt;
+    static constexpr int value = sizeof(IDX) == 2 ? 10 : 26;
+};
+
+__device__ __forceinline__ int wave_inclusive_scan(int v, const int lane)
+{
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1)
     {
-        const int v = __shfl_up(incl, off, 64);
+        const int u = __shfl_up(v, off, 64);
         if (lane >= off)
-            incl += v;
+            v += u;
     }
-    const int total = __builtin_amdgcn_readlane(incl, 63);
-    const int excl = incl - cnt;
-    for (int j = 0; j < cnt; ++j)
-        pairs[excl + j] = (IDX)(((uint32_t)lane << IDX_BITS) | (uint32_t)cand[j * R1_BLOCK + tid]);
-    __builtin_amdgcn_wave_barrier();
-    // Each flagged GROUP expands to its R1_GROUP_MAX member slots: 16 pairs x 4 members fill a
-    // trip; a lane takes pair (base + lane) / 4, member lane % 4.
+    return v;
+}
+
+// `total` (lane, group) pairs are in `pairs`: each expands to its R1_GROUP_MAX member slots —
+// 16 pairs x 4 members fill a trip; a lane takes pair (base + lane) / 4, member lane % 4.
+template <bool STATS, typename IDX>
+__device__ __forceinline__ void exact_trips(const R1DeviceScene &S, const V3 o, const V3 d, const int total, const IDX *pairs,
+                                            unsigned long long *best /* this wave's [64] */, const int lane, unsigned long long *wstat)
+{
+    constexpr int IDX_BITS = PairBits<IDX>::value;
     const int slots = total * R1_GROUP_MAX;
     if (STATS)
         wstat[2] += (unsigned long long)((slots + 63) >> 6);
@@ -268,12 +270,83 @@ __device__ __forceinline__ void cooperative_exact(const R1DeviceScene &S, const 
     __builtin_amdgcn_wave_barrier();
 }
 
+// Append path (big scenes): every lane holds `cnt` flagged group indices in cand[j][tid].
+template <bool STATS, typename IDX>
+__device__ __forceinline__ void cooperative_exact(const R1DeviceScene &S, const V3 o, const V3 d, int cnt, const uint32_t *cand,
+                                                  IDX *pairs /* this wave's [R1_PAIR_CAP] */, unsigned long long *best /* this wave's [64] */,
+                                                  const int tid, const int lane, unsigned long long *wstat)
+{
+    constexpr int IDX_BITS = PairBits<IDX>::value;
+    const int incl = wave_inclusive_scan(cnt, lane);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    const int excl = incl - cnt;
+    for (int j = 0; j < cnt; ++j)
+        pairs[excl + j] = (IDX)(((uint32_t)lane << IDX_BITS) | cand[j * R1_BLOCK + tid]);
+    __builtin_amdgcn_wave_barrier();
+    exact_trips<STATS, IDX>(S, o, d, total, pairs, best, lane, wstat);
+}
+
+// Bit path (<= 1023 groups): every lane holds `nwords` 32-bit flag words in words[w][tid]; bit
+// 31 - p of word w flags group gbase + 32 w + p.  More than R1_PAIR_CAP pairs in the wave (a
+// wave of rays that all skim rows of spheres) are worked off half a word at a time: 16 flags per
+// lane always fit.
+template <bool STATS, typename IDX>
+__device__ __forceinline__ void cooperative_bits(const R1DeviceScene &S, const V3 o, const V3 d, const uint32_t nwords, const uint32_t gbase,
+                                                 const uint32_t *words, IDX *pairs, unsigned long long *best, const int tid, const int lane,
+                                                 unsigned long long *wstat)
+{
+    constexpr int IDX_BITS = PairBits<IDX>::value;
+    int cnt = 0;
+    for (uint32_t w = 0; w < nwords; ++w)
+        cnt += __popc(words[w * R1_BLOCK + tid]);
+    const int incl = wave_inclusive_scan(cnt, lane);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    if (STATS)
+        wstat[9] += (unsigned long long)cnt;
+    if (total == 0)
+        return;
+    if (total <= R1_PAIR_CAP)
+    {
+        int pos = incl - cnt;
+        for (uint32_t w = 0; w < nwords; ++w)
+        {
+            uint32_t word = words[w * R1_BLOCK + tid];
+            while (word)
+            {
+                const int p = __clz((int)word);
+                word &= ~(0x80000000u >> p);
+                pairs[pos++] = (IDX)(((uint32_t)lane << IDX_BITS) | (gbase + 32u * w + (uint32_t)p));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        exact_trips<STATS, IDX>(S, o, d, total, pairs, best, lane, wstat);
+        return;
+    }
+    for (uint32_t seg = 0; seg < 2u * nwords; ++seg)
+    {
+        const uint32_t w = seg >> 1;
+        uint32_t word = words[w * R1_BLOCK + tid] & ((seg & 1u) ? 0x0000FFFFu : 0xFFFF0000u);
+        const int c2 = __popc(word);
+        const int incl2 = wave_inclusive_scan(c2, lane);
+        const int total2 = __builtin_amdgcn_readlane(incl2, 63);
+        int pos = incl2 - c2;
+        while (word)
+        {
+            const int p = __clz((int)word);
+            word &= ~(0x80000000u >> p);
+            pairs[pos++] = (IDX)(((uint32_t)lane << IDX_BITS) | (gbase + 32u * w + (uint32_t)p));
+        }
+        __builtin_amdgcn_wave_barrier();
+        exact_trips<STATS, IDX>(S, o, d, total2, pairs, best, lane, wstat);
+    }
+}
+
 // ---- sweep, prefilter form -----------------------------------------------------------------
 // (formula and slack: see the comment block above)  Called by all 64 lanes; lanes with
 // alive == false never flag a candidate but help in the cooperative exact phase.
 template <bool STATS, typename IDX, bool BLOCK_SYNC>
 __device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const bool alive, const V3 o, const V3 d, float &t_max,
-                                                int &hit_index, IDX *cand /* [R1_CAND_CAP][R1_BLOCK] */,
+                                                int &hit_index, uint32_t *cand /* flag words [R1_BIT_WORDS][R1_BLOCK], or (big scenes) flagged groups [R1_CAND_CAP][R1_BLOCK] */,
                                                 IDX *pairs /* [R1_BLOCK/64][R1_PAIR_CAP] */,
                                                 unsigned long long *best /* [R1_BLOCK] */, f4 *tile /* BLOCK_SYNC: [2][R1_TILE_F4] */,
                                                 const int tid, unsigned long long *wstat)
@@ -328,13 +401,29 @@ __device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const bo
             }                                                                                                          \
             _Pragma("unroll") for (int u = 0; u < 8; ++u) if (c[u])                                                    \
             {                                                                                                          \
-                cand[cnt * R1_BLOCK + tid] = (IDX)(8 * (CH) + u);                                                      \
+                cand[cnt * R1_BLOCK + tid] = (uint32_t)(8 * (CH) + u);                                                 \
                 ++cnt;                                                                                                 \
             }                                                                                                          \
         }                                                                                                              \
     }
     if (!BLOCK_SYNC)
     {
+        // Flags are kept as BITS, one per group, shifted into a per-lane word by the carry of the
+        // compare (v_cmp + v_addc: bits = 2 bits + flag): no branch, no per-flag bookkeeping in
+        // the sweep; a word goes to LDS every 32 groups and the wave works a batch of
+        // R1_BIT_WORDS words (256 groups) off at a time in cooperative_bits.
+#define R1_FLAG(QV, KS) asm volatile("v_cmp_le_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(QV), "s"(KS) : "vcc");
+#define R1_PAIR_BITS(L, B)                                                                                             \
+    {                                                                                                                  \
+        const v2f cx = {L[B + 0], L[B + 1]}, cy = {L[B + 2], L[B + 3]}, cz = {L[B + 4], L[B + 5]};                     \
+        const v2f nb = __builtin_elementwise_fma(cz, dzz, __builtin_elementwise_fma(cy, dyy, __builtin_elementwise_fma(cx, dxx, nod))); \
+        const v2f t = __builtin_elementwise_fma(cz, mzz, __builtin_elementwise_fma(cy, myy, __builtin_elementwise_fma(cx, mxx, ooa))); \
+        const v2f q = __builtin_elementwise_fma(nb, nb, -t);                                                           \
+        R1_FLAG(q.x, L[B + 6]) R1_FLAG(q.y, L[B + 7])                                                                  \
+    }
+#define R1_CHUNK_BITS(L0, L1) {R1_PAIR_BITS(L0, 0) R1_PAIR_BITS(L0, 8) R1_PAIR_BITS(L1, 0) R1_PAIR_BITS(L1, 8)}
+        uint32_t bits = 0;
+        uint32_t nwords = 0, gbase = 0; // wave-uniform
         // two register sets (A, B) alternate: while one chunk is evaluated the next one loads
         f16 a0 = tab[0], a1 = tab[1];
         uint32_t ch = 0;
@@ -346,14 +435,41 @@ __device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const bo
             asm volatile("" ::"s"(a0[0]), "s"(a1[0]));
             const f16 b0 = tab[2 * ch + 2], b1 = tab[2 * ch + 3];
             __builtin_amdgcn_sched_barrier(0);
-            R1_CHUNK_EVAL(a0, a1, ch)
+            R1_CHUNK_BITS(a0, a1)
             asm volatile("" ::"s"(b0[0]), "s"(b1[0]));
             a0 = tab[2 * ch + 4], a1 = tab[2 * ch + 5];
             __builtin_amdgcn_sched_barrier(0);
-            R1_CHUNK_EVAL(b0, b1, ch + 1)
+            R1_CHUNK_BITS(b0, b1)
+            if (ch & 2u) // 32 groups since the last word
+            {
+                cand[nwords * R1_BLOCK + tid] = bits;
+                if (++nwords == R1_BIT_WORDS)
+                {
+                    cooperative_bits<STATS, IDX>(S, o, d, nwords, gbase, cand, wpairs, wbest, tid, lane, wstat);
+                    nwords = 0;
+                    gbase = (ch + 2) * 8;
+                }
+            }
         }
         if (ch < chunks) // odd number of chunks: the last one is already in set A
-            R1_CHUNK_EVAL(a0, a1, ch)
+        {
+            R1_CHUNK_BITS(a0, a1)
+            ++ch;
+        }
+        if (ch & 3u) // a partial word: left-align it
+        {
+            cand[nwords * R1_BLOCK + tid] = bits << (32u - 8u * (ch & 3u));
+            ++nwords;
+        }
+        if (STATS)
+        {
+            wstat[5] += __builtin_readcyclecounter() - wstat[15];
+            wstat[15] = __builtin_readcyclecounter();
+        }
+        cooperative_bits<STATS, IDX>(S, o, d, nwords, gbase, cand, wpairs, wbest, tid, lane, wstat);
+#undef R1_CHUNK_BITS
+#undef R1_PAIR_BITS
+#undef R1_FLAG
     }
     else
     {
@@ -395,13 +511,8 @@ __device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const bo
     }
 #undef R1_CHUNK_EVAL
 #undef R1_PAIR
-    if (STATS)
-    {
-        wstat[5] += __builtin_readcyclecounter() - wstat[15];
-        wstat[15] = __builtin_readcyclecounter();
-        wstat[9] += (unsigned long long)cnt; // per-lane (summed over lanes at the end)
-    }
-    cooperative_exact<STATS, IDX>(S, o, d, cnt, cand, wpairs, wbest, tid, lane, wstat);
+    if (BLOCK_SYNC)
+        cooperative_exact<STATS, IDX>(S, o, d, cnt, cand, wpairs, wbest, tid, lane, wstat);
     const unsigned long long key = wbest[lane];
     if (key != NONE)
     {
@@ -516,7 +627,7 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
         wstat[14] = __builtin_readcyclecounter();
     }
     __shared__ uint32_t s_stack[BIG ? 1 : R1_STACK_WORDS * R1_BLOCK];
-    __shared__ IDX s_cand[R1_CAND_CAP * R1_BLOCK];
+    __shared__ uint32_t s_cand[(BIG ? R1_CAND_CAP : R1_BIT_WORDS) * R1_BLOCK];
     __shared__ IDX s_pairs[(R1_BLOCK / 64) * R1_PAIR_CAP];
     const uint32_t gstride = gridDim.x * R1_BLOCK, gtid = blockIdx.x * R1_BLOCK + threadIdx.x;
     __shared__ unsigned long long s_best[R1_BLOCK];

@@ -21,6 +21,8 @@ for variant in (binding.VARIANT_PREFILTER, binding.VARIANT_STATS):
 st = rend.last_stats()
 info = rend.launch_info()
 waves = info["blocks"] * 4
+st["groups"] = info["groups"]
+st["spheres_active"] = info["spheres_active"]
 st["rays"] = rays
 st["waves"] = waves
 st["lane_utilisation_at_sweep"] = st["alive_lanes"] / (64.0 * st["wave_iterations"])
