@@ -75,7 +75,7 @@ struct r1_context
 
     // scene
     DevBuf sweep, exact, shade, mat, members;
-    uint32_t n_active = 0, n_sweep = 0, n_padded_scene = 0, n_groups = 0;
+    uint32_t n_active = 0, n_sweep = 0, n_padded_scene = 0, n_groups = 0, n_multi = 0;
     std::vector<uint32_t> active_to_scene;
     R1DeviceCamera cam;
     bool have_scene = false;
@@ -315,7 +315,8 @@ static std::vector<R1Group> build_groups(uint32_t na, const std::vector<double> 
             double rmin = 1e300;
             for (uint32_t a : tryg)
                 rmin = fmin(rmin, r[a]);
-            ok = g.radius <= R1_GROUP_RATIO * rmin;
+            static const double ratio = getenv("R1_GROUP_RATIO") ? atof(getenv("R1_GROUP_RATIO")) : R1_GROUP_RATIO;
+            ok = g.radius <= (ratio < R1_GROUP_RATIO ? ratio : R1_GROUP_RATIO) * rmin; // the slack analysis needs <= R1_GROUP_RATIO
         }
         if (ok)
             cur = tryg;
@@ -367,8 +368,14 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
         ax[a] = s->center_x[i], ay[a] = s->center_y[i], az[a] = s->center_z[i];
         ar_[a] = 1.0 / (double)s->inv_radius[i]; // inv_radius != 0 means radius > 0 (soa_sphere.cpp:81)
     }
-    const std::vector<R1Group> groups = build_groups(na, ax, ay, az, ar_);
+    std::vector<R1Group> groups = build_groups(na, ax, ay, az, ar_);
+    // multi-member groups first: a flagged group with id >= n_multi is a single sphere and takes
+    // one member slot of the exact phase instead of R1_GROUP_MAX
+    std::stable_partition(groups.begin(), groups.end(), [](const R1Group &g) { return g.n > 1; });
     const uint32_t ng = (uint32_t)groups.size();
+    uint32_t n_multi = 0;
+    while (n_multi < ng && groups[n_multi].n > 1)
+        ++n_multi;
 
     // small scenes: whole 8-group chunks + one prefetch chunk; big scenes: whole LDS tiles + one
     // prefetch tile
@@ -436,6 +443,7 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
     R1_HIP(hipMemcpy(c->mat.p, mat.data(), mat.size() * 4, hipMemcpyHostToDevice));
     R1_HIP(hipMemcpy(c->members.p, members.data(), members.size() * 4, hipMemcpyHostToDevice));
     c->n_groups = ng;
+    c->n_multi = n_multi;
 
     c->n_active = na;
     c->n_sweep = ns;
@@ -529,6 +537,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     a.scene.members = (const uint32_t *)c->members.p;
     a.scene.n_active = c->n_active;
     a.scene.n_sweep = c->n_sweep;
+    a.scene.n_multi = c->n_multi;
     a.cam = c->cam;
     a.width = p->width, a.height = p->height, a.spp = p->spp, a.max_bounces = p->max_bounces;
     a.seed = p->seed;

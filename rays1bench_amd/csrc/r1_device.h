@@ -42,6 +42,7 @@ struct R1DeviceScene
     const float4 *shade;   // {inv_radius, albedo_r, albedo_g, albedo_b}
     const uint32_t *members; // [n_sweep (+pad)][R1_GROUP_MAX] active indices of a group's spheres, 0xFFFFFFFF = none
     const float4 *mat;     // {bit_cast<float>(type), param, 1/ref_idx, ((1-ref)/(1+ref))^2} (last two: dielectrics)
+    uint32_t n_multi;      // groups [0, n_multi) have 2..R1_GROUP_MAX members, groups >= n_multi exactly one
     uint32_t n_active;     // real entries
     uint32_t n_sweep;      // GROUPS, padded to a multiple of 8 (+8 prefetch); big scenes: of R1_TILE_SPHERES (+ one tile)
 };

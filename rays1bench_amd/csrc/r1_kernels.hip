@@ -239,24 +239,27 @@ __device__ __forceinline__ int wave_inclusive_scan(int v, const int lane)
     return v;
 }
 
-// `total` (lane, group) pairs are in `pairs`: each expands to its R1_GROUP_MAX member slots —
-// 16 pairs x 4 members fill a trip; a lane takes pair (base + lane) / 4, member lane % 4.
-template <bool STATS, typename IDX>
+// `total` (lane, group) pairs are in `pairs`.  SLOTS == R1_GROUP_MAX: each pair expands to its
+// member slots — 16 pairs x 4 members fill a trip, a lane takes pair (base + lane) / 4, member
+// lane % 4.  SLOTS == 1: the pairs are single-sphere groups, one lane each.
+template <bool STATS, typename IDX, int SLOTS>
 __device__ __forceinline__ void exact_trips(const R1DeviceScene &S, const V3 o, const V3 d, const int total, const IDX *pairs,
                                             unsigned long long *best /* this wave's [64] */, const int lane, unsigned long long *wstat)
 {
     constexpr int IDX_BITS = PairBits<IDX>::value;
-    const int slots = total * R1_GROUP_MAX;
+    constexpr int SHIFT = SLOTS == 1 ? 0 : 2;
+    static_assert(SLOTS == 1 || (SLOTS == 4 && R1_GROUP_MAX == 4), "member-slot mapping assumes 4 spheres per group");
+    const int slots = total * SLOTS;
     if (STATS)
         wstat[2] += (unsigned long long)((slots + 63) >> 6);
     for (int base = 0; base < slots; base += 64) // wave-uniform trip count
     {
-        const int j = (base + lane) >> 2;
+        const int j = (base + lane) >> SHIFT;
         const bool have_pair = j < total;
         const uint32_t pr = have_pair ? (uint32_t)pairs[j] : ((uint32_t)lane << IDX_BITS);
         const int owner = (int)(pr >> IDX_BITS);
         const uint32_t grp = pr & ((1u << IDX_BITS) - 1u);
-        const uint32_t idx = have_pair ? S.members[(size_t)grp * R1_GROUP_MAX + (lane & (R1_GROUP_MAX - 1))] : 0xFFFFFFFFu;
+        const uint32_t idx = have_pair ? S.members[(size_t)grp * R1_GROUP_MAX + (SLOTS == 1 ? 0 : (lane & (R1_GROUP_MAX - 1)))] : 0xFFFFFFFFu;
         V3 ro, rd;
         ro.x = __shfl(o.x, owner, 64), ro.y = __shfl(o.y, owner, 64), ro.z = __shfl(o.z, owner, 64);
         rd.x = __shfl(d.x, owner, 64), rd.y = __shfl(d.y, owner, 64), rd.z = __shfl(d.z, owner, 64);
@@ -283,7 +286,7 @@ __device__ __forceinline__ void cooperative_exact(const R1DeviceScene &S, const 
     for (int j = 0; j < cnt; ++j)
         pairs[excl + j] = (IDX)(((uint32_t)lane << IDX_BITS) | cand[j * R1_BLOCK + tid]);
     __builtin_amdgcn_wave_barrier();
-    exact_trips<STATS, IDX>(S, o, d, total, pairs, best, lane, wstat);
+    exact_trips<STATS, IDX, R1_GROUP_MAX>(S, o, d, total, pairs, best, lane, wstat);
 }
 
 // Bit path (<= 1023 groups): every lane holds `nwords` 32-bit flag words in words[w][tid]; bit
@@ -296,18 +299,29 @@ __device__ __forceinline__ void cooperative_bits(const R1DeviceScene &S, const V
                                                  unsigned long long *wstat)
 {
     constexpr int IDX_BITS = PairBits<IDX>::value;
+    // flags of multi-member groups (ids < n_multi) and of single spheres are counted apart: the
+    // former go to the front of `pairs`, the latter to its back, and are worked off with 4 and 1
+    // member slot per pair.  Both counts ride one prefix sum (16 bits each).
     int cnt = 0;
     for (uint32_t w = 0; w < nwords; ++w)
-        cnt += __popc(words[w * R1_BLOCK + tid]);
-    const int incl = wave_inclusive_scan(cnt, lane);
-    const int total = __builtin_amdgcn_readlane(incl, 63);
-    if (STATS)
-        wstat[9] += (unsigned long long)cnt;
-    if (total == 0)
-        return;
-    if (total <= R1_PAIR_CAP)
     {
-        int pos = incl - cnt;
+        const uint32_t word = words[w * R1_BLOCK + tid];
+        const int first = (int)(gbase + 32u * w);      // group of bit 31
+        const int nm = (int)S.n_multi - first;         // groups of this word below n_multi
+        const uint32_t multi_mask = nm >= 32 ? 0xFFFFFFFFu : (nm <= 0 ? 0u : ~(0xFFFFFFFFu >> nm));
+        cnt += __popc(word & multi_mask) + (__popc(word & ~multi_mask) << 16);
+    }
+    const int incl = wave_inclusive_scan(cnt, lane);
+    const int totals = __builtin_amdgcn_readlane(incl, 63);
+    const int total_m = totals & 0xFFFF, total_s = totals >> 16;
+    if (STATS)
+        wstat[9] += (unsigned long long)((cnt & 0xFFFF) + (cnt >> 16));
+    if (totals == 0)
+        return;
+    if (total_m + total_s <= R1_PAIR_CAP)
+    {
+        int pos_m = (incl - cnt) & 0xFFFF;
+        int pos_s = R1_PAIR_CAP - 1 - ((incl - cnt) >> 16); // singles grow down from the end
         for (uint32_t w = 0; w < nwords; ++w)
         {
             uint32_t word = words[w * R1_BLOCK + tid];
@@ -315,11 +329,17 @@ __device__ __forceinline__ void cooperative_bits(const R1DeviceScene &S, const V
             {
                 const int p = __clz((int)word);
                 word &= ~(0x80000000u >> p);
-                pairs[pos++] = (IDX)(((uint32_t)lane << IDX_BITS) | (gbase + 32u * w + (uint32_t)p));
+                const uint32_t g = gbase + 32u * w + (uint32_t)p;
+                const IDX v = (IDX)(((uint32_t)lane << IDX_BITS) | g);
+                if (g < S.n_multi)
+                    pairs[pos_m++] = v;
+                else
+                    pairs[pos_s--] = v;
             }
         }
         __builtin_amdgcn_wave_barrier();
-        exact_trips<STATS, IDX>(S, o, d, total, pairs, best, lane, wstat);
+        exact_trips<STATS, IDX, R1_GROUP_MAX>(S, o, d, total_m, pairs, best, lane, wstat);
+        exact_trips<STATS, IDX, 1>(S, o, d, total_s, pairs + (R1_PAIR_CAP - total_s), best, lane, wstat);
         return;
     }
     for (uint32_t seg = 0; seg < 2u * nwords; ++seg)
@@ -337,7 +357,7 @@ __device__ __forceinline__ void cooperative_bits(const R1DeviceScene &S, const V
             pairs[pos++] = (IDX)(((uint32_t)lane << IDX_BITS) | (gbase + 32u * w + (uint32_t)p));
         }
         __builtin_amdgcn_wave_barrier();
-        exact_trips<STATS, IDX>(S, o, d, total2, pairs, best, lane, wstat);
+        exact_trips<STATS, IDX, R1_GROUP_MAX>(S, o, d, total2, pairs, best, lane, wstat);
     }
 }
 
