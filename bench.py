@@ -256,12 +256,14 @@ def main():
                          "launch_overlap": trace_ms_sum * 1e-3 / elapsed,
                          "achieved_aggregate": alg_bytes * frames / elapsed / 1e9,
                          "frac_aggregate": alg_bytes * frames / elapsed / 1e9 / HBM_PEAK_GBS,
-                         "note": "algorithmic bytes = rays x 16 B x N_pad (the streaming model of the reference's sweep); the sphere "
-                                 "table is SGPR/cache resident, so this fraction can exceed 1 and the binding roof is fp32 VALU",
+                         "note": "algorithmic bytes = rays x 16 B x N_pad (the streaming model of the reference's sweep); the "
+                                 "table is SGPR/cache resident and spheres are tested in groups of <= 4 behind a conservative "
+                                 "bound, so this fraction can exceed 1 and the binding roof is fp32 VALU issue",
                          "valu": {"achieved_tflops": local_rays * 16.0 * n_pad * frames / elapsed / 1e12, "peak_tflops": FP32_VECTOR_PEAK_TF,
                                   "frac": local_rays * 16.0 * n_pad * frames / elapsed / 1e12 / FP32_VECTOR_PEAK_TF,
-                                  "note": "16 flop per ray-sphere test as the reference counts them (SURVEY.md §8d); aggregate over "
-                                          "the timed region (all launches / elapsed); one isolated launch (--inflight 1): DESIGN.md §7"}},
+                                  "note": "16 flop per ray-sphere test of the reference's sweep (SURVEY.md §8d), i.e. counting the sphere "
+                                          "tests the group tests stand for; aggregate over the timed region (all launches / "
+                                          "elapsed); one isolated launch (--inflight 1): DESIGN.md §7"}},
         }
         if check is not None:
             out["check"] = check
