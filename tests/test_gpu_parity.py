@@ -419,3 +419,59 @@ def test_sphere_count_edges_vs_oracle(renderer, n_active):
     assert img.tobytes() == oimg.tobytes()
     if n_active == 0:
         assert rays == w * h * spp  # every primary ray sees the sky
+
+
+# ---- adversarial geometry for the conservative group prefilter -------------------------------------
+
+
+@pytest.mark.parametrize("case", ["mixed_radii", "far_camera", "dense_cluster", "tiny_spheres", "nested"])
+def test_grouped_prefilter_is_exact_on_random_scenes(renderer, case):
+    """Random scenes that stress the slack analysis (radius ratios, |o| >> scene, touching and
+    nested spheres): the default kernel (groups + prefilter) must be bit-identical to the
+    REFERENCE-form kernel (every sphere, reference arithmetic) and to the oracle."""
+    rng = np.random.default_rng({"mixed_radii": 1, "far_camera": 2, "dense_cluster": 3, "tiny_spheres": 4, "nested": 5}[case])
+    w, h, spp = 72, 48, 3
+    base = r1.create_small_scene(w, h)
+    cam = base.camera_array().copy()
+    n = 300
+    if case == "mixed_radii":
+        c = rng.uniform(-12, 12, (n, 3))
+        rad = np.exp(rng.uniform(np.log(0.02), np.log(6.0), n))
+    elif case == "far_camera":
+        c = rng.uniform(-8, 8, (n, 3))
+        rad = rng.uniform(0.2, 0.8, n)
+        shift = np.array([700.0, 260.0, 410.0], np.float32)
+        c = c + shift  # same view, everything far from the world origin: |o| and |c| ~ 850
+        cam[0:3] += shift
+        cam[3:6] += shift
+    elif case == "dense_cluster":
+        c = rng.normal(0, 1.2, (n, 3))
+        rad = rng.uniform(0.05, 0.35, n)
+    elif case == "tiny_spheres":
+        c = rng.uniform(-3, 3, (n, 3))
+        rad = np.exp(rng.uniform(np.log(1e-3), np.log(0.05), n))
+    else:  # nested: shells around a few centres, equal centres with different radii
+        centres = rng.uniform(-4, 4, (12, 3))
+        c = centres[rng.integers(0, 12, n)]
+        rad = rng.uniform(0.05, 2.5, n)
+    c = c.astype(np.float32)
+    rad = rad.astype(np.float32)
+    mt = rng.integers(0, 3, n).astype(np.uint8)
+    arr = {"center_x": c[:, 0].copy(), "center_y": c[:, 1].copy(), "center_z": c[:, 2].copy(), "radius_sq": rad * rad,
+           "inv_radius": (np.float32(1.0) / rad).astype(np.float32), "mat_type": mt,
+           "albedo_r": rng.uniform(0.1, 0.95, n).astype(np.float32), "albedo_g": rng.uniform(0.1, 0.95, n).astype(np.float32),
+           "albedo_b": rng.uniform(0.1, 0.95, n).astype(np.float32),
+           "mat_param": np.where(mt == 2, rng.uniform(1.1, 2.4, n), rng.uniform(0, 1, n)).astype(np.float32)}
+    pad = (-n) % 8
+    for k in arr:
+        fill = {"center_x": 999999999.0, "center_y": 999999999.0, "center_z": 999999999.0, "mat_type": 255}.get(k, 0)
+        arr[k] = np.concatenate([arr[k], np.full(pad, fill, arr[k].dtype)])
+    sa = r1o.SceneArrays(arr, cam)
+    renderer.set_scene_raw(_as_cscene(sa), _as_ccamera(sa))
+    p = r1.make_params(w, h, spp, 1234)
+    got = renderer.render_samples(p)
+    ref = renderer.render_samples(r1.make_params(w, h, spp, 1234, variant=binding.VARIANT_REFERENCE))
+    assert got[1] == ref[1] and got[2].tobytes() == ref[2].tobytes() and got[0].tobytes() == ref[0].tobytes()
+    oimg, orays, osamples = r1o.render_frame(sa, oparams(p), want_samples=True)
+    assert got[1] == orays and got[2].tobytes() == osamples.tobytes()
+    assert renderer.launch_info()["groups"] <= n
