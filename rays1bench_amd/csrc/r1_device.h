@@ -13,6 +13,7 @@
 #define R1_CHUNK 256        // most samples a wave takes from the global queue per atomic
 #define R1_CHUNK_MIN 32      // fewest (end of the queue: guided self-scheduling)
 #define R1_GROUP_MAX 4         // spheres per group (level 1 of the sweep tests group bounds)
+#define R1_GROUP_MIN_SPHERES 128 // scenes with fewer active spheres are swept ungrouped
 #define R1_GROUP_RATIO 3.5     // a group's bounding radius stays within this factor of its smallest member radius
 #define R1_SAMPLES_PER_LANE 48 // grid sizing: samples each lane should get (see enqueue_frame)
 #define R1_TILE_SPHERES 512    // big-scene sweep: spheres per LDS tile (8 KB in pair layout), two tiles in LDS
