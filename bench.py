@@ -195,6 +195,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    submit = time.perf_counter() - t0  # host time to enqueue the frames (must stay below `elapsed`)
     fence()
     elapsed = time.perf_counter() - t0
     trace_ms_sum, total_ms_sum, frames = 0.0, 0.0, 0
@@ -246,7 +247,7 @@ def main():
                        "rays_per_step": rays_per_step, "tiles": "32x32, tile t -> rank t % N",
                        "parallelism": f"tile-split x{n}" + (" + one RCCL all-gather per frame (pixels + ray counts)" if n > 1 else ""),
                        "workgroups": info["blocks"], "threads_per_workgroup": info["threads_per_block"],
-                       "frames_in_flight": len(slots)},
+                       "frames_in_flight": len(slots), "host_submit_ms_per_step": submit / args.steps * 1e3},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "r1_trace_kernel", "kernel_ms": kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes,
