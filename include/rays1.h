@@ -108,7 +108,10 @@ enum
     R1_VARIANT_REFERENCE = 1, /* pass 1 in the reference's exact arithmetic (rayweek1.cpp:190-202),
                                  no prefilter; slower, used to cross-check the default       */
     R1_VARIANT_PREFILTER = 2, /* conservative 8-op prefilter + exact re-test */
-    R1_VARIANT_STATS = 3      /* PREFILTER plus in-kernel phase/utilisation counters (diagnostic; r1_last_stats) */
+    R1_VARIANT_STATS = 3,     /* PREFILTER plus in-kernel phase/utilisation counters (diagnostic; r1_last_stats) */
+    R1_VARIANT_BVH = 4        /* optional spatial index (the reference has none, README.md:163): a conservative
+                                 box tree chooses the spheres given to the reference's per-sphere test; results
+                                 are bit-identical to the exhaustive sweeps   */
 };
 
 typedef struct r1_context r1_context; /* opaque: device, stream, events, workspace */

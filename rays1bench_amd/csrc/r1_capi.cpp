@@ -27,6 +27,17 @@ extern "C" hipError_t r1_launch_assemble(const void *blocks, void *rgb, int widt
 extern "C" hipError_t r1_trace_occupancy(int variant, int big, int *blocks_per_cu);
 extern "C" int r1_params_check(const r1_params *p); // r1_host.cpp
 
+// r1_bvh.cpp
+struct R1Bvh
+{
+    std::vector<float> nodes;
+    std::vector<float> prims;
+    std::vector<uint32_t> ids;
+    int max_depth = 0;
+    uint32_t n_leaves = 0;
+};
+void r1_build_bvh(uint32_t na, const float *cx, const float *cy, const float *cz, const float *rsq, int leaf_max, R1Bvh &out);
+
 // ---- errors ---------------------------------------------------------------------------------
 
 static thread_local char g_error[512] = "";
@@ -75,6 +86,9 @@ struct r1_context
 
     // scene
     DevBuf sweep, exact, shade, mat, members;
+    DevBuf bvh_nodes, bvh_prims, bvh_ids; // R1_VARIANT_BVH (r1_bvh.cpp)
+    uint32_t n_bvh_nodes = 0, n_bvh_leaves = 0;
+    int bvh_depth = 0;
     uint32_t n_active = 0, n_sweep = 0, n_padded_scene = 0, n_groups = 0, n_multi = 0;
     std::vector<uint32_t> active_to_scene;
     R1DeviceCamera cam;
@@ -86,7 +100,7 @@ struct r1_context
     bool tile_key_valid = false;
     uint32_t n_local_tiles = 0, total_samples = 0, full = 0;
 
-    int occupancy[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // [variant + 4*big]
+    int occupancy[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // [variant + 5*big]
     DevBuf gstack; // blocks per CU of the trace kernel, by variant
 
     r1_launch_info info;
@@ -182,6 +196,7 @@ extern "C" void r1_destroy(r1_context *c)
     if (c->stream)
         (void)hipStreamSynchronize(c->stream);
     release(c->sweep), release(c->exact), release(c->shade), release(c->mat), release(c->members);
+    release(c->bvh_nodes), release(c->bvh_prims), release(c->bvh_ids);
     release(c->gstack), release(c->counters), release(c->samples), release(c->image);
     for (hipEvent_t e : c->ring)
         (void)hipEventDestroy(e);
@@ -435,7 +450,25 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
         mat[4 * a + 3] = type == R1_MAT_DIELECTRIC ? r0 : 0.0f;
     }
 
+    // the optional spatial index over the same active spheres (R1_VARIANT_BVH)
+    R1Bvh bvh;
+    {
+        std::vector<float> fx(na ? na : 1), fy(na ? na : 1), fz(na ? na : 1), fr(na ? na : 1);
+        for (uint32_t a = 0; a < na; ++a)
+            fx[a] = exact[4 * a + 0], fy[a] = exact[4 * a + 1], fz[a] = exact[4 * a + 2], fr[a] = exact[4 * a + 3];
+        static const int leaf_env = getenv("R1_BVH_LEAF") ? atoi(getenv("R1_BVH_LEAF")) : 0;
+        r1_build_bvh(na, fx.data(), fy.data(), fz.data(), fr.data(), leaf_env > 0 ? leaf_env : R1_BVH_LEAF, bvh);
+        if (bvh.max_depth > R1_BVH_STACK)
+        {
+            r1_set_error("r1_set_scene: spatial index deeper (%d) than the traversal stack (%d)", bvh.max_depth, R1_BVH_STACK);
+            return R1_ELIMIT;
+        }
+    }
+
     int rc;
+    if ((rc = ensure(c->bvh_nodes, bvh.nodes.size() * 4)) || (rc = ensure(c->bvh_prims, bvh.prims.size() * 4)) ||
+        (rc = ensure(c->bvh_ids, bvh.ids.size() * 4)))
+        return rc;
     if ((rc = ensure(c->sweep, sweep.size() * 4)) || (rc = ensure(c->exact, exact.size() * 4)) ||
         (rc = ensure(c->shade, shade.size() * 4)) || (rc = ensure(c->mat, mat.size() * 4)) ||
         (rc = ensure(c->members, members.size() * 4)))
@@ -446,6 +479,12 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
     R1_HIP(hipMemcpy(c->shade.p, shade.data(), shade.size() * 4, hipMemcpyHostToDevice));
     R1_HIP(hipMemcpy(c->mat.p, mat.data(), mat.size() * 4, hipMemcpyHostToDevice));
     R1_HIP(hipMemcpy(c->members.p, members.data(), members.size() * 4, hipMemcpyHostToDevice));
+    R1_HIP(hipMemcpy(c->bvh_nodes.p, bvh.nodes.data(), bvh.nodes.size() * 4, hipMemcpyHostToDevice));
+    R1_HIP(hipMemcpy(c->bvh_prims.p, bvh.prims.data(), bvh.prims.size() * 4, hipMemcpyHostToDevice));
+    R1_HIP(hipMemcpy(c->bvh_ids.p, bvh.ids.data(), bvh.ids.size() * 4, hipMemcpyHostToDevice));
+    c->n_bvh_nodes = (uint32_t)(bvh.nodes.size() / 16);
+    c->n_bvh_leaves = bvh.n_leaves;
+    c->bvh_depth = bvh.max_depth;
     c->n_groups = ng;
     c->n_multi = n_multi;
 
@@ -523,7 +562,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     int rc = r1_params_check(p);
     if (rc)
         return rc;
-    const int variant = p->variant == R1_VARIANT_REFERENCE ? 1 : (p->variant == R1_VARIANT_STATS ? 3 : 2);
+    const int variant = p->variant == R1_VARIANT_REFERENCE ? 1 : p->variant == R1_VARIANT_STATS ? 3 : p->variant == R1_VARIANT_BVH ? 4 : 2;
     R1_HIP(hipSetDevice(c->device));
     if ((rc = prepare_tiles(c, p)))
         return rc;
@@ -542,6 +581,9 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     a.scene.n_active = c->n_active;
     a.scene.n_sweep = c->n_sweep;
     a.scene.n_multi = c->n_multi;
+    a.scene.bvh_nodes = (const float4 *)c->bvh_nodes.p;
+    a.scene.bvh_prims = (const float4 *)c->bvh_prims.p;
+    a.scene.bvh_ids = (const uint32_t *)c->bvh_ids.p;
     a.cam = c->cam;
     a.width = p->width, a.height = p->height, a.spp = p->spp, a.max_bounces = p->max_bounces;
     a.seed = p->seed;
@@ -563,9 +605,9 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     a.stats = variant == 3 ? (unsigned long long *)((char *)c->counters.p + 128) : nullptr;
 
     const int big = c->n_active > R1_MAX_ACTIVE_10BIT ? 1 : 0;
-    if (c->occupancy[variant + 4 * big] == 0)
-        R1_HIP(r1_trace_occupancy(variant, big, &c->occupancy[variant + 4 * big]));
-    int per_cu = c->occupancy[variant + 4 * big];
+    if (c->occupancy[variant + 5 * big] == 0)
+        R1_HIP(r1_trace_occupancy(variant, big, &c->occupancy[variant + 5 * big]));
+    int per_cu = c->occupancy[variant + 5 * big];
     if (per_cu < 1)
         per_cu = 1;
     if (per_cu > 8)

@@ -21,6 +21,8 @@
 #define R1_MAX_ACTIVE_10BIT 1023
 #define R1_MAX_ACTIVE (1u << 21) // big-scene kernels: 26-bit pair indices, limit kept at 2 M spheres
 #define R1_STACK_ENTRIES 51
+#define R1_BVH_STACK 32        // R1_VARIANT_BVH: per-lane traversal stack entries in LDS = most inner nodes on a path
+#define R1_BVH_LEAF 4          // spheres per leaf (<= 7)
 
 // Division of n < 2^31 by a launch constant: pow2 ? n >> shift : mulhi(n, mul) >> shift, with
 // mul = ceil(2^(32+shift) / d), shift = floor(log2 d) (exact for every n < 2^31; r1_capi.cpp).
@@ -46,6 +48,14 @@ struct R1DeviceScene
     uint32_t n_multi;      // groups [0, n_multi) have 2..R1_GROUP_MAX members, groups >= n_multi exactly one
     uint32_t n_active;     // real entries
     uint32_t n_sweep;      // GROUPS, padded to a multiple of 8 (+8 prefetch); big scenes: of R1_TILE_SPHERES (+ one tile)
+    // R1_VARIANT_BVH (r1_bvh.cpp): binary tree of boxes over the active spheres.  Node = 4 float4:
+    // {m0.xyz, w2} {e0.xyz, k} {m1.xyz, child0} {e1.xyz, child1}; child i has centre m_i and half
+    // extent e_i, inflated per ray by pad = w2 |m_i - o|^2 + k.  Child reference: bit 31 clear =
+    // inner node index; set = leaf, bits 28..30 sphere count, bits 0..27 first slot of
+    // bvh_prims {cx, cy, cz, radius_sq} / bvh_ids (active index).  Node 0 is the root.
+    const float4 *bvh_nodes;
+    const float4 *bvh_prims;
+    const uint32_t *bvh_ids;
 };
 
 struct R1DeviceCamera

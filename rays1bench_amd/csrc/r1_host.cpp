@@ -266,11 +266,12 @@ static int tiles_required(int tile, int size) // rayweek1.cpp:61-68
 extern "C" int r1_params_check(const r1_params *p)
 {
     if (!p || p->width <= 0 || p->height <= 0 || p->spp <= 0 || p->tile_w <= 0 || p->tile_h <= 0 || p->num_shards < 1 ||
-        p->shard < 0 || p->shard >= p->num_shards || p->max_bounces < 1 || p->max_bounces > R1_MAX_BOUNCES_LIMIT)
+        p->shard < 0 || p->shard >= p->num_shards || p->max_bounces < 1 || p->max_bounces > R1_MAX_BOUNCES_LIMIT ||
+        p->variant < R1_VARIANT_DEFAULT || p->variant > R1_VARIANT_BVH)
     {
-        r1_set_error("bad r1_params (size %dx%dx%d, tile %dx%d, shard %d/%d, max_bounces %d)", p ? p->width : 0, p ? p->height : 0,
-                     p ? p->spp : 0, p ? p->tile_w : 0, p ? p->tile_h : 0, p ? p->shard : 0, p ? p->num_shards : 0,
-                     p ? p->max_bounces : 0);
+        r1_set_error("bad r1_params (size %dx%dx%d, tile %dx%d, shard %d/%d, max_bounces %d, variant %d)", p ? p->width : 0,
+                     p ? p->height : 0, p ? p->spp : 0, p ? p->tile_w : 0, p ? p->tile_h : 0, p ? p->shard : 0, p ? p->num_shards : 0,
+                     p ? p->max_bounces : 0, p ? p->variant : 0);
         return R1_EINVAL;
     }
     if ((int64_t)p->width * p->height * p->spp >= (int64_t)1 << 31 || p->width > 65535 || p->height > 65535)

@@ -541,6 +541,94 @@ __device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const bo
     }
 }
 
+// ---- sweep through the optional spatial index (R1_VARIANT_BVH) -------------
+// Per-lane ordered traversal of the binary box tree built by r1_bvh.cpp.  Only the choice of
+// spheres presented to exact_offer differs from the exhaustive sweeps; the boxes are inflated
+// by pad = w2 |m - o|^2 + k (conservative with respect to the reference's fp32 test, see
+// r1_bvh.cpp) and a subtree is skipped only if its inflated box is missed or lies entirely
+// beyond the closest offer so far.  Result = minimum offer, ties to the lowest sphere index —
+// the reference's in-order rule (see exact_offer).  The traversal stack lives in LDS,
+// [entry][thread]; the builder bounds the tree depth by R1_BVH_STACK.
+#define R1_BVH_DONE 0xFFFFFFFFu
+__device__ __forceinline__ bool bvh_box(const float mx, const float my, const float mz, const float ex, const float ey, const float ez,
+                                        const float w2, const float k, const V3 o, const V3 inv, const float best, float &t_near)
+{
+    const float cx = mx - o.x, cy = my - o.y, cz = mz - o.z;
+    const float d2 = __fmaf_rn(cz, cz, __fmaf_rn(cy, cy, cx * cx));
+    const float pad = __fmaf_rn(w2, d2, k);
+    const float ax = cx * inv.x, ay = cy * inv.y, az = cz * inv.z;
+    const float bx = (ex + pad) * fabsf(inv.x), by = (ey + pad) * fabsf(inv.y), bz = (ez + pad) * fabsf(inv.z);
+    // NaN (0 x inf on an axis the ray does not move along) drops out of fmaxf/fminf: no constraint
+    const float tn = fmaxf(fmaxf(ax - bx, ay - by), az - bz);
+    const float tf = fminf(fminf(ax + bx, ay + by), az + bz);
+    t_near = tn;
+    return tn <= fminf(tf, best) && tf >= 0.0f;
+}
+
+__device__ __forceinline__ void sweep_bvh(const R1DeviceScene &S, const bool alive, const V3 o, const V3 d, float &t_max, int &hit_index,
+                                          uint32_t *trav, const int tid)
+{
+    const float4 *__restrict__ nodes = S.bvh_nodes;
+    const float4 *__restrict__ prims = S.bvh_prims;
+    const uint32_t *__restrict__ ids = S.bvh_ids;
+    const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    float best = FLT_MAX;
+    uint32_t best_id = 0xFFFFFFFFu;
+    uint32_t cur = alive ? 0u : R1_BVH_DONE;
+    int sp = 0;
+    while (cur != R1_BVH_DONE)
+    {
+        // inner nodes: descend to the nearer child, remember the farther one
+        while (!(cur & 0x80000000u))
+        {
+            const float4 n0 = nodes[4 * (size_t)cur + 0], n1 = nodes[4 * (size_t)cur + 1], n2 = nodes[4 * (size_t)cur + 2],
+                         n3 = nodes[4 * (size_t)cur + 3];
+            float tn0, tn1;
+            const bool h0 = bvh_box(n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, n0.w, n1.w, o, inv, best, tn0);
+            const bool h1 = bvh_box(n2.x, n2.y, n2.z, n3.x, n3.y, n3.z, n0.w, n1.w, o, inv, best, tn1);
+            const uint32_t c0 = __float_as_uint(n2.w), c1 = __float_as_uint(n3.w);
+            if (h0 && h1)
+            {
+                const bool swap = tn1 < tn0;
+                trav[sp * R1_BLOCK + tid] = swap ? c0 : c1;
+                ++sp;
+                cur = swap ? c1 : c0;
+            }
+            else if (h0)
+                cur = c0;
+            else if (h1)
+                cur = c1;
+            else if (sp > 0)
+                cur = trav[--sp * R1_BLOCK + tid];
+            else
+                cur = R1_BVH_DONE;
+        }
+        if (cur != R1_BVH_DONE)
+        {
+            const uint32_t first = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
+            for (uint32_t j = 0; j < cnt; ++j)
+            {
+                const float4 e4 = prims[first + j];
+                f4 e;
+                e.x = e4.x, e.y = e4.y, e.z = e4.z, e.w = e4.w;
+                const float t = exact_offer(e, o, d);
+                if (t <= best && t < FLT_MAX)
+                {
+                    const uint32_t id = ids[first + j];
+                    if (t < best || id < best_id)
+                        best = t, best_id = id;
+                }
+            }
+            cur = sp > 0 ? trav[--sp * R1_BLOCK + tid] : R1_BVH_DONE;
+        }
+    }
+    if (best_id != 0xFFFFFFFFu)
+    {
+        t_max = best;
+        hit_index = (int)best_id;
+    }
+}
+
 // Attenuation stack.  Small scenes: packed in LDS, three 10-bit sphere indices per word.  Big
 // scenes (> 1023 active spheres): one u32 per entry in a global workspace laid out
 // [entry][global thread] (coalesced); its traffic is nothing next to a 100 k-sphere sweep.
@@ -647,11 +735,12 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
         wstat[14] = __builtin_readcyclecounter();
     }
     __shared__ uint32_t s_stack[BIG ? 1 : R1_STACK_WORDS * R1_BLOCK];
-    __shared__ uint32_t s_cand[(BIG ? R1_CAND_CAP : R1_BIT_WORDS) * R1_BLOCK];
-    __shared__ IDX s_pairs[(R1_BLOCK / 64) * R1_PAIR_CAP];
+    __shared__ uint32_t s_cand[VARIANT == 2 ? (BIG ? R1_CAND_CAP : R1_BIT_WORDS) * R1_BLOCK : 1];
+    __shared__ IDX s_pairs[VARIANT == 2 ? (R1_BLOCK / 64) * R1_PAIR_CAP : 1];
+    __shared__ uint32_t s_trav[VARIANT == 4 ? R1_BVH_STACK * R1_BLOCK : 1];
     const uint32_t gstride = gridDim.x * R1_BLOCK, gtid = blockIdx.x * R1_BLOCK + threadIdx.x;
-    __shared__ unsigned long long s_best[R1_BLOCK];
-    __shared__ f4 s_tile[BIG ? 2 * R1_TILE_F4 : 1];
+    __shared__ unsigned long long s_best[VARIANT == 2 ? R1_BLOCK : 1];
+    __shared__ f4 s_tile[BIG && VARIANT == 2 ? 2 * R1_TILE_F4 : 1];
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
@@ -704,7 +793,7 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
             q_next += min((uint32_t)__popcll(need), avail);
             need = __ballot(!alive);
         }
-        if (BIG)
+        if (BIG && VARIANT == 2)
         {
             // lock-step workgroup: leave together (every wave must reach the sweep's barriers)
             if (!__syncthreads_or(alive ? 1 : 0))
@@ -742,6 +831,8 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
             if (alive)
                 sweep_reference(A.scene, p.o, p.d, t_hit, hit);
         }
+        else if (VARIANT == 4)
+            sweep_bvh(A.scene, alive, p.o, p.d, t_hit, hit, s_trav, tid);
         else
             sweep_prefilter<STATS, IDX, BIG>(A.scene, alive, p.o, p.d, t_hit, hit, s_cand, s_pairs, s_best, s_tile, tid, wstat);
         if (STATS)
@@ -960,7 +1051,11 @@ __global__ void __launch_bounds__(256)
 extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int blocks, hipStream_t stream)
 {
     const bool big = args->scene.n_active > R1_MAX_ACTIVE_10BIT;
-    if (variant == 1 && big)
+    if (variant == 4 && big)
+        hipLaunchKernelGGL((r1_trace_kernel<4, false, true>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
+    else if (variant == 4)
+        hipLaunchKernelGGL((r1_trace_kernel<4, false, false>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
+    else if (variant == 1 && big)
         hipLaunchKernelGGL((r1_trace_kernel<1, false, true>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
     else if (variant == 1)
         hipLaunchKernelGGL((r1_trace_kernel<1, false, false>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
@@ -996,6 +1091,10 @@ extern "C" hipError_t r1_launch_assemble(const void *blocks, void *rgb, int widt
 
 extern "C" hipError_t r1_trace_occupancy(int variant, int big, int *blocks_per_cu)
 {
+    if (variant == 4 && big)
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<4, false, true>, R1_BLOCK, 0);
+    if (variant == 4)
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<4, false, false>, R1_BLOCK, 0);
     if (variant == 1 && big)
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<1, false, true>, R1_BLOCK, 0);
     if (variant == 1)

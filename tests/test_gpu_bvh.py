@@ -1,0 +1,240 @@
+"""GPU parity tests of the optional spatial index (R1_VARIANT_BVH).
+
+The reference has no acceleration structure; the box tree only chooses which spheres are given
+to the reference's per-sphere test, and must never lose a sphere the reference would hit: every
+test here requires BIT-IDENTICAL samples, ray counts and pixels against the exhaustive kernels
+(R1_VARIANT_REFERENCE: every sphere in the reference's arithmetic) and against the CPU oracle.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import rays1bench_amd as r1
+from rays1bench_amd import binding
+import r1o
+
+pytestmark = pytest.mark.gpu
+
+MAKE = {"small": r1.create_small_scene, "medium": r1.create_medium_scene, "large": r1.create_large_scene}
+BVH = binding.VARIANT_BVH
+
+
+@pytest.fixture(scope="module")
+def renderer():
+    assert r1.device_count() >= 1, "no HIP device: the product has no CPU fallback"
+    r = r1.Renderer(0)
+    yield r
+    r.close()
+
+
+def oracle_scene(sc):
+    return r1o.SceneArrays.from_c(sc.spheres, sc.camera)
+
+
+def oparams(p):
+    return r1o.make_params(p.width, p.height, p.spp, p.seed, p.max_bounces, p.tile_w, p.tile_h, p.shard, p.num_shards)
+
+
+def _as_cscene(sa):
+    cs = binding.CScene()
+    cs.count = sa.count
+    for k in r1o.SCENE_F32:
+        setattr(cs, k, sa.arrays[k].ctypes.data_as(C.POINTER(C.c_float)))
+    cs.mat_type = sa.arrays["mat_type"].ctypes.data_as(C.POINTER(C.c_uint8))
+    return cs
+
+
+def _as_ccamera(sa):
+    cc = binding.CCamera()
+    C.memmove(C.byref(cc), C.byref(sa.camera), C.sizeof(cc))
+    return cc
+
+
+def same(a, b):
+    return a[1] == b[1] and a[2].tobytes() == b[2].tobytes() and a[0].tobytes() == b[0].tobytes()
+
+
+def pad8(arr):
+    n = len(arr["center_x"])
+    pad = (-n) % 8 or (8 if n == 0 else 0)
+    for k in arr:
+        fill = {"center_x": 999999999.0, "center_y": 999999999.0, "center_z": 999999999.0, "mat_type": 255}.get(k, 0)
+        arr[k] = np.concatenate([arr[k], np.full(pad, fill, arr[k].dtype)])
+    return arr
+
+
+def random_materials(rng, n):
+    mt = rng.integers(0, 3, n).astype(np.uint8)
+    return {"mat_type": mt,
+            "albedo_r": rng.uniform(0.1, 0.95, n).astype(np.float32), "albedo_g": rng.uniform(0.1, 0.95, n).astype(np.float32),
+            "albedo_b": rng.uniform(0.1, 0.95, n).astype(np.float32),
+            "mat_param": np.where(mt == 2, rng.uniform(1.1, 2.4, n), rng.uniform(0, 1, n)).astype(np.float32)}
+
+
+def spheres(c, rad, rng):
+    c = np.asarray(c, np.float32)
+    rad = np.asarray(rad, np.float32)
+    arr = {"center_x": c[:, 0].copy(), "center_y": c[:, 1].copy(), "center_z": c[:, 2].copy(), "radius_sq": rad * rad,
+           "inv_radius": (np.float32(1.0) / rad).astype(np.float32)}
+    arr.update(random_materials(rng, len(rad)))
+    return pad8(arr)
+
+
+@pytest.mark.parametrize("name,w,h,spp,seed", [("small", 160, 120, 16, 7), ("medium", 333, 211, 5, 123456789), ("large", 256, 192, 12, 0)])
+def test_bvh_full_frame_bit_exact_vs_oracle(renderer, name, w, h, spp, seed):
+    sc = MAKE[name](w, h)
+    renderer.set_scene(sc)
+    p = r1.make_params(w, h, spp, seed, variant=BVH)
+    img, rays, samples = renderer.render_samples(p)
+    oimg, orays, osamples = r1o.render_frame(oracle_scene(sc), oparams(p), want_samples=True)
+    differing = (samples.view(np.uint32) != osamples.view(np.uint32)).any(1)
+    assert differing.mean() <= 1e-5, differing.sum()  # pow5 vs glibc powf, as for the default kernel
+    assert abs(rays - orays) <= 51 * differing.sum()
+
+
+@pytest.mark.parametrize("name", ["small", "medium", "large"])
+def test_bvh_equals_exhaustive_sweep_at_the_baseline_size(renderer, name):
+    """1200x800x10 (BASELINE configs 2/3): the tree-driven kernel and the default (grouped
+    exhaustive sweep) agree on every one of the 9.6 M samples."""
+    w, h, spp = 1200, 800, 10
+    renderer.set_scene(MAKE[name](w, h))
+    a = renderer.render_samples(r1.make_params(w, h, spp, 10001))
+    b = renderer.render_samples(r1.make_params(w, h, spp, 10001, variant=BVH))
+    assert same(a, b)
+
+
+@pytest.mark.parametrize("n_active", [0, 1, 2, 4, 5, 9, 1023, 1024])
+def test_bvh_sphere_count_edges(renderer, n_active):
+    w, h, spp = 64, 48, 2
+    src = r1.create_grid_scene(w, h, 36, 30)
+    arr = src.arrays()
+    keep = np.nonzero(arr["inv_radius"] != 0)[0][-n_active:] if n_active else np.zeros(0, np.int64)
+    sub = pad8({k: v[keep] for k, v in arr.items()})
+    sa = r1o.SceneArrays(sub, src.camera_array())
+    renderer.set_scene_raw(_as_cscene(sa), _as_ccamera(sa))
+    got = renderer.render_samples(r1.make_params(w, h, spp, 9, variant=BVH))
+    ref = renderer.render_samples(r1.make_params(w, h, spp, 9, variant=binding.VARIANT_REFERENCE))
+    assert same(got, ref)
+    oimg, orays, osamples = r1o.render_frame(sa, oparams(r1.make_params(w, h, spp, 9)), want_samples=True)
+    assert got[1] == orays and got[2].tobytes() == osamples.tobytes()
+
+
+CASES = ["mixed_radii", "far_camera", "dense_cluster", "tiny_spheres", "nested", "noise_dominated", "coincident", "collinear"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_bvh_is_exact_on_adversarial_scenes(renderer, case):
+    """Geometry that stresses the pad analysis of r1_bvh.cpp: radius ratios of 300, a scene
+    850 units from the world origin, touching/nested/coincident spheres, and spheres so small
+    and far that the reference's fp32 discriminant is mostly rounding noise (its 'hits' reach
+    well outside the geometric sphere — the tree must still present those spheres)."""
+    rng = np.random.default_rng(100 + CASES.index(case))
+    w, h, spp = 72, 48, 3
+    base = r1.create_small_scene(w, h)
+    cam = base.camera_array().copy()
+    n = 300
+    if case == "mixed_radii":
+        c, rad = rng.uniform(-12, 12, (n, 3)), np.exp(rng.uniform(np.log(0.02), np.log(6.0), n))
+    elif case == "far_camera":
+        shift = np.array([700.0, 260.0, 410.0], np.float32)
+        c, rad = rng.uniform(-8, 8, (n, 3)) + shift, rng.uniform(0.2, 0.8, n)
+        cam[0:3] += shift
+        cam[3:6] += shift
+    elif case == "dense_cluster":
+        c, rad = rng.normal(0, 1.2, (n, 3)), rng.uniform(0.05, 0.35, n)
+    elif case == "tiny_spheres":
+        c, rad = rng.uniform(-3, 3, (n, 3)), np.exp(rng.uniform(np.log(1e-3), np.log(0.05), n))
+    elif case == "nested":
+        centres = rng.uniform(-4, 4, (12, 3))
+        c, rad = centres[rng.integers(0, 12, n)], rng.uniform(0.05, 2.5, n)
+    elif case == "noise_dominated":
+        # radius 2e-3 seen from ~600 units: discriminant error ~ 2^-22 * 3.6e5 >> r^2 = 4e-6
+        shift = np.array([-420.0, 380.0, 210.0], np.float32)
+        c, rad = rng.uniform(-1.5, 1.5, (n, 3)) + shift, np.full(n, 2e-3)
+        c[:40] = rng.uniform(-1.5, 1.5, (40, 3))  # and some near the camera
+        rad[:20] = 0.4
+        rad[-1] = 300.0  # a big mirror ball behind, sends rays back at the far cluster
+        c[-1] = np.array([0.0, -302.0, 0.0])
+    elif case == "coincident":
+        c, rad = np.repeat(rng.uniform(-3, 3, (n // 6, 3)), 6, axis=0), np.repeat(rng.uniform(0.1, 0.6, n // 6), 6)
+    else:  # collinear: all centres on one axis-parallel line (degenerate boxes, one split axis)
+        c = np.zeros((n, 3))
+        c[:, 0] = rng.uniform(-20, 20, n)
+        c[:, 1] = 0.25
+        rad = rng.uniform(0.05, 0.3, n)
+    arr = spheres(c, rad, rng)
+    sa = r1o.SceneArrays(arr, cam)
+    renderer.set_scene_raw(_as_cscene(sa), _as_ccamera(sa))
+    got = renderer.render_samples(r1.make_params(w, h, spp, 1234, variant=BVH))
+    ref = renderer.render_samples(r1.make_params(w, h, spp, 1234, variant=binding.VARIANT_REFERENCE))
+    assert same(got, ref)
+    oimg, orays, osamples = r1o.render_frame(sa, oparams(r1.make_params(w, h, spp, 1234)), want_samples=True)
+    assert got[1] == orays and got[2].tobytes() == osamples.tobytes()
+
+
+def test_bvh_axis_parallel_rays(renderer):
+    """horizontal = vertical = 0 and no lens: every primary ray is exactly (0, 0, -1), so two
+    reciprocal direction components are infinite (0 x inf = NaN inside the slab test)."""
+    rng = np.random.default_rng(7)
+    w, h, spp = 48, 32, 4
+    n = 200
+    c = rng.uniform(-2, 2, (n, 3))
+    c[:, 2] -= 6
+    c[:20, :2] = 0  # several exactly on the axis the rays run along
+    arr = spheres(c, rng.uniform(0.05, 0.5, n), rng)
+    cam = np.zeros(22, np.float32)
+    cam[3:6] = (0, 0, -1)                      # lower_left - origin = direction
+    cam[12:15], cam[15:18], cam[18:21] = (1, 0, 0), (0, 1, 0), (0, 0, 1)
+    sa = r1o.SceneArrays(arr, cam)
+    renderer.set_scene_raw(_as_cscene(sa), _as_ccamera(sa))
+    got = renderer.render_samples(r1.make_params(w, h, spp, 3, variant=BVH))
+    ref = renderer.render_samples(r1.make_params(w, h, spp, 3, variant=binding.VARIANT_REFERENCE))
+    assert same(got, ref)
+    assert got[1] > w * h * spp  # the axis spheres are hit
+
+
+@pytest.mark.parametrize("gw,gh,w,h,spp", [(64, 40, 160, 120, 4), (33, 31, 96, 64, 3)])
+def test_bvh_big_scene_bit_exact_vs_oracle(renderer, gw, gh, w, h, spp):
+    sc = r1.create_grid_scene(w, h, gw, gh)
+    renderer.set_scene(sc)
+    p = r1.make_params(w, h, spp, 31337, variant=BVH)
+    img, rays, samples = renderer.render_samples(p)
+    oimg, orays, osamples = r1o.render_frame(oracle_scene(sc), oparams(p), want_samples=True)
+    assert rays == orays
+    assert samples.tobytes() == osamples.tobytes()
+    assert img.tobytes() == oimg.tobytes()
+
+
+def test_bvh_config5_100k_spheres_equals_the_lds_tiled_sweep(renderer):
+    """BASELINE config 5's scene (100 004 spheres): a whole small frame, tree vs exhaustive
+    LDS-tiled sweep, every sample; plus oracle spot checks."""
+    w, h, spp = 160, 90, 2
+    sc = r1.create_grid_scene(w, h, 400, 250)
+    renderer.set_scene(sc)
+    a = renderer.render_samples(r1.make_params(w, h, spp, 5))
+    b = renderer.render_samples(r1.make_params(w, h, spp, 5, variant=BVH))
+    assert same(a, b)
+    sa = oracle_scene(sc)
+    rng = np.random.default_rng(1)
+    xs, ys, ss = rng.integers(0, w, 200), rng.integers(0, h, 200), rng.integers(0, spp, 200)
+    rgb, orays = r1o.trace_samples(sa, w, h, 5, xs, ys, ss)
+    got = b[2][(ys * w + xs) * spp + ss]
+    assert (got[:, 3].copy().view(np.uint32) == orays).all()
+    assert got[:, :3].tobytes() == rgb.tobytes()
+
+
+def test_bvh_shards_and_tiles(renderer):
+    """The variant goes through the same tiling/sharding path: tile size and shard count do not
+    change the frame."""
+    w, h, spp = 200, 120, 3
+    renderer.set_scene(r1.create_large_scene(w, h))
+    base = renderer.render(r1.make_params(w, h, spp, 77))
+    full = renderer.render(r1.make_params(w, h, spp, 77, variant=BVH))
+    assert full[0].tobytes() == base[0].tobytes() and full[1] == base[1]
+    odd = renderer.render(r1.make_params(w, h, spp, 77, tile_w=24, tile_h=40, variant=BVH))
+    assert odd[0].tobytes() == base[0].tobytes() and odd[1] == base[1]
+    total = 0
+    for shard in range(3):
+        total += renderer.render(r1.make_params(w, h, spp, 77, shard=shard, num_shards=3, variant=BVH))[1]
+    assert total == base[1]
