@@ -104,14 +104,16 @@ typedef struct r1_params
 
 enum
 {
-    R1_VARIANT_DEFAULT = 0,   /* fastest validated kernel                                   */
+    R1_VARIANT_DEFAULT = 0,   /* fastest validated kernel: PREFILTER up to 1 023 hittable spheres, BVH above */
     R1_VARIANT_REFERENCE = 1, /* pass 1 in the reference's exact arithmetic (rayweek1.cpp:190-202),
                                  no prefilter; slower, used to cross-check the default       */
     R1_VARIANT_PREFILTER = 2, /* conservative 8-op prefilter + exact re-test */
     R1_VARIANT_STATS = 3,     /* PREFILTER plus in-kernel phase/utilisation counters (diagnostic; r1_last_stats) */
-    R1_VARIANT_BVH = 4        /* optional spatial index (the reference has none, README.md:163): a conservative
+    R1_VARIANT_BVH = 4,       /* optional spatial index (the reference has none, README.md:163): a conservative
                                  box tree chooses the spheres given to the reference's per-sphere test; results
                                  are bit-identical to the exhaustive sweeps   */
+    R1_VARIANT_BVH_STATS = 5  /* BVH plus traversal counters (diagnostic; r1_last_stats slots [2] node-loop trips,
+                                 [3] leaf-loop trips, [5] sphere tests, [9] node visits)                          */
 };
 
 typedef struct r1_context r1_context; /* opaque: device, stream, events, workspace */
@@ -213,10 +215,27 @@ typedef struct r1_launch_info
     int32_t spheres_padded; /* `count` of the scene (N_pad of the reference)     */
     int32_t groups;         /* sphere groups the first sweep level tests          */
     uint64_t samples;       /* pixel-samples traced                              */
+    int32_t kernel;         /* R1_VARIANT_* the launch actually ran (DEFAULT resolved) */
+    int32_t bvh_nodes;      /* inner nodes of the spatial index                   */
+    int32_t bvh_leaves;
+    int32_t bvh_depth;      /* inner nodes on the longest root-to-leaf path       */
 } r1_launch_info;
 int r1_last_launch_info(r1_context *ctx, r1_launch_info *out);
 
 /* ---- host-side helpers of the drop-in (no GPU needed) ------------------------------ */
+
+/* Shape of the spatial index R1_VARIANT_BVH uses (r1_bvh.cpp; the reference has no such
+ * structure, README.md:163).  Builds it on the host exactly as r1_set_scene does.  Optional
+ * outputs: `nodes_out` receives 16 floats per inner node {m0.xyz, w2 | e0.xyz, k | m1.xyz,
+ * child0 | e1.xyz, child1} (child: bit 31 = leaf, bits 28..30 sphere count, bits 0..27 first
+ * leaf slot; else inner node index), `ids_out[slot]` the scene index of the sphere in each
+ * leaf slot.  leaf_max <= 0 selects the build's default. */
+typedef struct r1_bvh_info
+{
+    int32_t nodes, leaves, depth, stack_entries, spheres;
+} r1_bvh_info;
+int r1_bvh_describe(const r1_scene *scene, int32_t leaf_max, r1_bvh_info *info, float *nodes_out, size_t nodes_cap, uint32_t *ids_out,
+                    size_t ids_cap);
 
 enum
 {

@@ -15,7 +15,7 @@ LIBDIR = os.path.join(HERE, "lib")
 
 R1_OK, R1_EINVAL, R1_ENODEVICE, R1_EHIP, R1_ENOMEM, R1_ELIMIT = 0, -1, -2, -3, -4, -5
 SCENE_SMALL, SCENE_MEDIUM, SCENE_LARGE, SCENE_GRID = 0, 1, 2, 3
-VARIANT_DEFAULT, VARIANT_REFERENCE, VARIANT_PREFILTER, VARIANT_STATS, VARIANT_BVH = 0, 1, 2, 3, 4
+VARIANT_DEFAULT, VARIANT_REFERENCE, VARIANT_PREFILTER, VARIANT_STATS, VARIANT_BVH, VARIANT_BVH_STATS = 0, 1, 2, 3, 4, 5
 
 
 class R1Error(RuntimeError):
@@ -48,7 +48,12 @@ class Params(C.Structure):
 
 class LaunchInfo(C.Structure):
     _fields_ = [("compute_units", C.c_int32), ("blocks", C.c_int32), ("threads_per_block", C.c_int32),
-                ("spheres_active", C.c_int32), ("spheres_padded", C.c_int32), ("groups", C.c_int32), ("samples", C.c_uint64)]
+                ("spheres_active", C.c_int32), ("spheres_padded", C.c_int32), ("groups", C.c_int32), ("samples", C.c_uint64),
+                ("kernel", C.c_int32), ("bvh_nodes", C.c_int32), ("bvh_leaves", C.c_int32), ("bvh_depth", C.c_int32)]
+
+
+class BvhInfo(C.Structure):
+    _fields_ = [("nodes", C.c_int32), ("leaves", C.c_int32), ("depth", C.c_int32), ("stack_entries", C.c_int32), ("spheres", C.c_int32)]
 
 
 def make_params(width, height, spp, seed=10001, max_bounces=50, tile_w=32, tile_h=32, shard=0, num_shards=1, variant=0):
@@ -93,6 +98,7 @@ SYMBOLS = [
     ("r1_host_scene_destroy", None, [C.c_void_p]),
     ("r1_host_scene_spheres", C.POINTER(CScene), [C.c_void_p]),
     ("r1_host_scene_camera", C.POINTER(CCamera), [C.c_void_p]),
+    ("r1_bvh_describe", C.c_int, [C.POINTER(CScene), C.c_int32, C.POINTER(BvhInfo), _f32p, C.c_size_t, C.POINTER(C.c_uint32), C.c_size_t]),
     ("r1_tga_write_rgb24", C.c_int, [C.c_char_p, C.c_int32, C.c_int32, _u8p]),
     ("r1_log_results", C.c_int, [C.c_char_p, C.c_char_p, _dblp, _u64p, C.c_int32]),
 ]
@@ -279,6 +285,17 @@ def tile_count(params):
     a, b = C.c_int32(), C.c_int32()
     _check(lib().r1_tile_count(C.byref(params), C.byref(a), C.byref(b)))
     return int(a.value), int(b.value)
+
+
+def bvh_describe(cscene, leaf_max=0):
+    """Host-side build of the R1_VARIANT_BVH index: (info dict, nodes float32[n,16], ids uint32[spheres])."""
+    info = BvhInfo()
+    _check(lib().r1_bvh_describe(C.byref(cscene), leaf_max, C.byref(info), None, 0, None, 0))
+    nodes = np.zeros((info.nodes, 16), np.float32)
+    ids = np.zeros(max(info.spheres, 1), np.uint32)
+    _check(lib().r1_bvh_describe(C.byref(cscene), leaf_max, C.byref(info), nodes.ctypes.data_as(_f32p), nodes.size,
+                                 ids.ctypes.data_as(C.POINTER(C.c_uint32)), ids.size))
+    return {k: int(getattr(info, k)) for k, _ in BvhInfo._fields_}, nodes, ids[:info.spheres]
 
 
 class RESULT:

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include "r1_device.h"
+#include "../../include/rays1.h"
 
 #include <algorithm>
 #include <cmath>
@@ -325,4 +326,44 @@ void r1_build_bvh(uint32_t na, const float *cx, const float *cy, const float *cz
     // keep the prim table non-empty and 16-byte padded for the loader
     if (out.prims.empty())
         out.prims.assign(4, 0.0f), out.ids.assign(1, 0u);
+}
+
+// Host-only view of the index (include/rays1.h): what r1_set_scene would build for this scene.
+extern "C" int r1_bvh_describe(const r1_scene *s, int32_t leaf_max, r1_bvh_info *info, float *nodes_out, size_t nodes_cap, uint32_t *ids_out,
+                               size_t ids_cap)
+{
+    if (!s || !info || !s->center_x || !s->center_y || !s->center_z || !s->radius_sq || !s->inv_radius)
+        return R1_EINVAL;
+    std::vector<float> x, y, z, r;
+    std::vector<uint32_t> scene_index;
+    for (uint32_t i = 0; i < s->count; ++i)
+        if (s->inv_radius[i] != 0)
+        {
+            x.push_back(s->center_x[i]), y.push_back(s->center_y[i]), z.push_back(s->center_z[i]), r.push_back(s->radius_sq[i]);
+            scene_index.push_back(i);
+        }
+    const uint32_t na = (uint32_t)x.size();
+    if (na == 0)
+        x.push_back(0), y.push_back(0), z.push_back(0), r.push_back(0);
+    R1Bvh b;
+    r1_build_bvh(na, x.data(), y.data(), z.data(), r.data(), leaf_max > 0 ? leaf_max : R1_BVH_LEAF, b);
+    info->nodes = (int32_t)(b.nodes.size() / 16);
+    info->leaves = (int32_t)b.n_leaves;
+    info->depth = b.max_depth;
+    info->stack_entries = R1_BVH_STACK;
+    info->spheres = (int32_t)na;
+    if (nodes_out)
+    {
+        if (nodes_cap < b.nodes.size())
+            return R1_ELIMIT;
+        memcpy(nodes_out, b.nodes.data(), b.nodes.size() * 4);
+    }
+    if (ids_out)
+    {
+        if (ids_cap < na)
+            return R1_ELIMIT;
+        for (uint32_t i = 0; i < na; ++i)
+            ids_out[i] = scene_index[b.ids[i]]; // leaf slot -> index into the caller's scene arrays
+    }
+    return R1_OK;
 }

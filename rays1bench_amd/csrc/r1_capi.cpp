@@ -100,7 +100,7 @@ struct r1_context
     bool tile_key_valid = false;
     uint32_t n_local_tiles = 0, total_samples = 0, full = 0;
 
-    int occupancy[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // [variant + 5*big]
+    int occupancy[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // [variant + 6*big]
     DevBuf gstack; // blocks per CU of the trace kernel, by variant
 
     r1_launch_info info;
@@ -562,7 +562,21 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     int rc = r1_params_check(p);
     if (rc)
         return rc;
-    const int variant = p->variant == R1_VARIANT_REFERENCE ? 1 : p->variant == R1_VARIANT_STATS ? 3 : p->variant == R1_VARIANT_BVH ? 4 : 2;
+    // kernel selection.  DEFAULT = the fastest validated kernel for the scene: the grouped
+    // exhaustive sweep up to 1 023 hittable spheres (the reference's own regime, MAX_SPHERES 1024,
+    // rayweek1.cpp:174), the box tree above (41-56x the LDS-tiled sweep at 100 k spheres, same
+    // pixels); PREFILTER always forces the exhaustive sweep.
+    const bool big_scene = c->n_active > R1_MAX_ACTIVE_10BIT;
+    int variant = 2;
+    switch (p->variant)
+    {
+    case R1_VARIANT_REFERENCE: variant = 1; break;
+    case R1_VARIANT_STATS: variant = 3; break;
+    case R1_VARIANT_BVH: variant = 4; break;
+    case R1_VARIANT_BVH_STATS: variant = 5; break;
+    case R1_VARIANT_DEFAULT: variant = big_scene ? 4 : 2; break;
+    default: variant = 2; break;
+    }
     R1_HIP(hipSetDevice(c->device));
     if ((rc = prepare_tiles(c, p)))
         return rc;
@@ -602,12 +616,12 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     a.queue = (uint32_t *)c->counters.p;
     a.samples = (float4 *)c->samples.p;
     a.num_rays = (unsigned long long *)d_rays;
-    a.stats = variant == 3 ? (unsigned long long *)((char *)c->counters.p + 128) : nullptr;
+    a.stats = (variant == 3 || variant == 5) ? (unsigned long long *)((char *)c->counters.p + 128) : nullptr;
 
     const int big = c->n_active > R1_MAX_ACTIVE_10BIT ? 1 : 0;
-    if (c->occupancy[variant + 5 * big] == 0)
-        R1_HIP(r1_trace_occupancy(variant, big, &c->occupancy[variant + 5 * big]));
-    int per_cu = c->occupancy[variant + 5 * big];
+    if (c->occupancy[variant + 6 * big] == 0)
+        R1_HIP(r1_trace_occupancy(variant, big, &c->occupancy[variant + 6 * big]));
+    int per_cu = c->occupancy[variant + 6 * big];
     if (per_cu < 1)
         per_cu = 1;
     if (per_cu > 8)
@@ -642,7 +656,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
         a.gstack = (uint32_t *)c->gstack.p;
     }
     R1_HIP(hipMemsetAsync(c->counters.p, 0, 64, st));
-    if (variant == 3)
+    if (variant == 3 || variant == 5)
         R1_HIP(hipMemsetAsync((char *)c->counters.p + 128, 0, 128, st));
     R1_HIP(hipMemsetAsync(d_rays, 0, 8, st));
     R1_HIP(hipEventRecord(e0, st));
@@ -672,6 +686,11 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     c->info.spheres_padded = (int32_t)c->n_padded_scene;
     c->info.groups = (int32_t)c->n_groups;
     c->info.samples = c->total_samples;
+    c->info.kernel = variant == 1 ? R1_VARIANT_REFERENCE : variant == 3 ? R1_VARIANT_STATS : variant == 4 ? R1_VARIANT_BVH
+                     : variant == 5 ? R1_VARIANT_BVH_STATS : R1_VARIANT_PREFILTER;
+    c->info.bvh_nodes = (int32_t)c->n_bvh_nodes;
+    c->info.bvh_leaves = (int32_t)c->n_bvh_leaves;
+    c->info.bvh_depth = c->bvh_depth;
     return R1_OK;
 }
 

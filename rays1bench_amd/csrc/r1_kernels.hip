@@ -565,8 +565,11 @@ __device__ __forceinline__ bool bvh_box(const float mx, const float my, const fl
     return tn <= fminf(tf, best) && tf >= 0.0f;
 }
 
+// STATS (diagnostic build): wstat[2] wave trips of the node loop, [3] wave trips of the leaf
+// sphere loop, [9] node visits summed over lanes, [5] sphere tests summed over lanes.
+template <bool STATS>
 __device__ __forceinline__ void sweep_bvh(const R1DeviceScene &S, const bool alive, const V3 o, const V3 d, float &t_max, int &hit_index,
-                                          uint32_t *trav, const int tid)
+                                          uint32_t *trav, const int tid, unsigned long long *wstat)
 {
     const float4 *__restrict__ nodes = S.bvh_nodes;
     const float4 *__restrict__ prims = S.bvh_prims;
@@ -581,6 +584,12 @@ __device__ __forceinline__ void sweep_bvh(const R1DeviceScene &S, const bool ali
         // inner nodes: descend to the nearer child, remember the farther one
         while (!(cur & 0x80000000u))
         {
+            if (STATS)
+            {
+                wstat[9] += 1;
+                if ((tid & 63) == __ffsll((long long)__ballot(1)) - 1)
+                    wstat[2] += 1;
+            }
             const float4 n0 = nodes[4 * (size_t)cur + 0], n1 = nodes[4 * (size_t)cur + 1], n2 = nodes[4 * (size_t)cur + 2],
                          n3 = nodes[4 * (size_t)cur + 3];
             float tn0, tn1;
@@ -608,6 +617,12 @@ __device__ __forceinline__ void sweep_bvh(const R1DeviceScene &S, const bool ali
             const uint32_t first = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
             for (uint32_t j = 0; j < cnt; ++j)
             {
+                if (STATS)
+                {
+                    wstat[5] += 1;
+                    if ((tid & 63) == __ffsll((long long)__ballot(1)) - 1)
+                        wstat[3] += 1;
+                }
                 const float4 e4 = prims[first + j];
                 f4 e;
                 e.x = e4.x, e.y = e4.y, e.z = e4.z, e.w = e4.w;
@@ -832,7 +847,7 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
                 sweep_reference(A.scene, p.o, p.d, t_hit, hit);
         }
         else if (VARIANT == 4)
-            sweep_bvh(A.scene, alive, p.o, p.d, t_hit, hit, s_trav, tid);
+            sweep_bvh<STATS>(A.scene, alive, p.o, p.d, t_hit, hit, s_trav, tid, wstat);
         else
             sweep_prefilter<STATS, IDX, BIG>(A.scene, alive, p.o, p.d, t_hit, hit, s_cand, s_pairs, s_best, s_tile, tid, wstat);
         if (STATS)
@@ -961,6 +976,18 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
         for (int off = 32; off > 0; off >>= 1)
             c9 += __shfl_down(c9, off, 64);
         wstat[9] = c9;
+        if (VARIANT == 4)
+        {
+            // per-lane counters of sweep_bvh
+            const int slots[3] = {2, 3, 5};
+            for (int q = 0; q < 3; ++q)
+            {
+                unsigned long long c = wstat[slots[q]];
+                for (int off = 32; off > 0; off >>= 1)
+                    c += __shfl_down(c, off, 64);
+                wstat[slots[q]] = c;
+            }
+        }
         if (lane == 0 && A.stats)
         {
             for (int i = 0; i < 10; ++i)
@@ -1051,7 +1078,11 @@ __global__ void __launch_bounds__(256)
 extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int blocks, hipStream_t stream)
 {
     const bool big = args->scene.n_active > R1_MAX_ACTIVE_10BIT;
-    if (variant == 4 && big)
+    if (variant == 5 && big)
+        hipLaunchKernelGGL((r1_trace_kernel<4, true, true>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
+    else if (variant == 5)
+        hipLaunchKernelGGL((r1_trace_kernel<4, true, false>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
+    else if (variant == 4 && big)
         hipLaunchKernelGGL((r1_trace_kernel<4, false, true>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
     else if (variant == 4)
         hipLaunchKernelGGL((r1_trace_kernel<4, false, false>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
@@ -1091,6 +1122,10 @@ extern "C" hipError_t r1_launch_assemble(const void *blocks, void *rgb, int widt
 
 extern "C" hipError_t r1_trace_occupancy(int variant, int big, int *blocks_per_cu)
 {
+    if (variant == 5 && big)
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<4, true, true>, R1_BLOCK, 0);
+    if (variant == 5)
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<4, true, false>, R1_BLOCK, 0);
     if (variant == 4 && big)
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<4, false, true>, R1_BLOCK, 0);
     if (variant == 4)

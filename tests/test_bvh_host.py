@@ -1,0 +1,167 @@
+"""CPU tests of the spatial index builder (r1_bvh.cpp through r1_bvh_describe; no GPU).
+
+Structure: every hittable sphere sits in exactly one leaf slot, child boxes contain their
+spheres, depth fits the kernel's traversal stack.  Conservativeness: a numpy re-statement of the
+kernel's traversal rule (inflated slab test, r1_kernels.hip::bvh_box) must present every sphere
+whose fp32 reference test can offer a hit (clear sign bit of the discriminant and a root
+beyond t_min, rayweek1.cpp:192-204, :294-313) — checked against
+brute force over all spheres for random and adversarial rays."""
+import numpy as np
+import pytest
+
+import rays1bench_amd as r1
+from rays1bench_amd import binding
+
+F = np.float32
+LEAF = 0x80000000
+
+
+def scene_arrays(sc):
+    a = sc.arrays()
+    return a
+
+
+def walk(nodes):
+    """Yields (node, child_slot, ref, m, e, w2, k) for every child reference in the tree."""
+    stack = [0]
+    seen = set()
+    while stack:
+        n = stack.pop()
+        assert n not in seen
+        seen.add(n)
+        row = nodes[n]
+        refs = row.view(np.uint32)
+        for c, (mo, eo, ro) in enumerate(((0, 4, 11), (8, 12, 15))):
+            ref = int(refs[ro])
+            yield n, c, ref, row[mo:mo + 3].astype(np.float64), row[eo:eo + 3].astype(np.float64), float(row[3]), float(row[7])
+            if not ref & LEAF:
+                stack.append(ref)
+    assert len(seen) == len(nodes)
+
+
+def leaf_slots(ref):
+    first, cnt = ref & 0x0FFFFFFF, (ref >> 28) & 7
+    return range(first, first + cnt)
+
+
+def subtree_slots(nodes, ref):
+    if ref & LEAF:
+        return list(leaf_slots(ref))
+    row = nodes[ref].view(np.uint32)
+    return subtree_slots(nodes, int(row[11])) + subtree_slots(nodes, int(row[15]))
+
+
+@pytest.mark.parametrize("kind,gw,gh", [("small", 0, 0), ("medium", 0, 0), ("large", 0, 0), ("grid", 64, 40), ("grid", 400, 250)])
+def test_tree_structure(kind, gw, gh):
+    sc = {"small": r1.create_small_scene, "medium": r1.create_medium_scene, "large": r1.create_large_scene}[kind](1200, 800) \
+        if kind != "grid" else r1.create_grid_scene(1920, 1080, gw, gh)
+    a = sc.arrays()
+    info, nodes, ids = binding.bvh_describe(sc.spheres.contents)
+    active = np.nonzero(a["inv_radius"] != 0)[0]
+    assert info["spheres"] == len(active)
+    assert sorted(ids.tolist()) == active.tolist()          # each hittable sphere exactly once, placeholders never
+    assert 1 <= info["depth"] <= info["stack_entries"]
+    c = np.stack([a["center_x"], a["center_y"], a["center_z"]], 1).astype(np.float64)
+    r = np.sqrt(a["radius_sq"].astype(np.float64))
+    n_leaf = 0
+    for n, ci, ref, m, e, w2, k in walk(nodes):
+        if ref & LEAF:
+            n_leaf += ((ref >> 28) & 7) > 0
+            slots = list(leaf_slots(ref))
+            assert len(slots) <= 4
+        elif len(nodes) <= 2000:
+            slots = subtree_slots(nodes, ref)
+        else:
+            continue  # big trees: leaves only (the inner boxes are unions of their children's by construction)
+        for s in slots:
+            i = ids[s]
+            assert (c[i] - r[i] >= m - e - 1e-12).all() and (c[i] + r[i] <= m + e + 1e-12).all()
+        assert w2 > 0 and k > 0
+    assert n_leaf == info["leaves"]
+    if kind == "grid" and gw == 400:
+        assert info["depth"] <= 24 and info["spheres"] == 100004
+
+
+def ref_flagged(cx, cy, cz, rsq, o, d):
+    """Spheres that can offer a hit: clear sign bit of the reference's fp32 discriminant
+    (rayweek1.cpp:192-204) and a root beyond t_min (:294-313), vectorised over spheres."""
+    cox, coy, coz = (cx - o[0]).astype(F), (cy - o[1]).astype(F), (cz - o[2]).astype(F)
+
+    def fma(a, b, c):  # exactly rounded fp32 fma through float64 (products of two fp32 are exact in fp64;
+        return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(F)  # double rounding is harmless for a superset test
+
+    nb = fma(coz, np.full_like(coz, d[2]), fma(coy, np.full_like(coy, d[1]), (cox * d[0]).astype(F)))
+    cc = (fma(coz, coz, fma(coy, coy, (cox * cox).astype(F))) - rsq).astype(F)
+    discr = ((nb * nb).astype(F) - cc).astype(F)
+    ok = ~np.signbit(discr)
+    root = np.sqrt(np.where(ok, discr, 0).astype(F)).astype(F)
+    t1, t2 = (nb - root).astype(F), (nb + root).astype(F)
+    return ok & ((t1 > F(0.001)) | (t2 > F(0.001)))
+
+
+def traverse(nodes, o, d):
+    """The kernel's visit rule without distance pruning: leaf slots the ray is shown."""
+    o = o.astype(F)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = (F(1) / d.astype(F)).astype(F)
+        out = []
+        stack = [0]
+        while stack:
+            n = stack.pop()
+            row = nodes[n]
+            refs = row.view(np.uint32)
+            w2, k = row[3], row[7]
+            for mo, eo, ro in ((0, 4, 11), (8, 12, 15)):
+                com = (row[mo:mo + 3] - o).astype(F)
+                d2 = F(com[2] * com[2] + F(com[1] * com[1] + F(com[0] * com[0])))
+                pad = F(w2 * d2 + k)
+                a = (com * inv).astype(F)
+                b = ((row[eo:eo + 3] + pad).astype(F) * np.abs(inv)).astype(F)
+                tn = np.fmax(np.fmax(a[0] - b[0], a[1] - b[1]), a[2] - b[2])
+                tf = np.fmin(np.fmin(a[0] + b[0], a[1] + b[1]), a[2] + b[2])
+                if tn <= tf and tf >= 0:
+                    ref = int(refs[ro])
+                    if ref & LEAF:
+                        out.extend(leaf_slots(ref))
+                    else:
+                        stack.append(ref)
+    return out
+
+
+@pytest.mark.parametrize("kind", ["large", "grid", "far_tiny"])
+def test_traversal_rule_presents_every_sphere_the_reference_flags(kind):
+    rng = np.random.default_rng(5)
+    if kind == "large":
+        sc = r1.create_large_scene(1200, 800)
+    elif kind == "grid":
+        sc = r1.create_grid_scene(1920, 1080, 120, 80)
+    else:
+        sc = r1.create_grid_scene(1920, 1080, 120, 80)
+    a = sc.arrays()
+    info, nodes, ids = binding.bvh_describe(sc.spheres.contents)
+    cx, cy, cz, rsq = a["center_x"], a["center_y"], a["center_z"], a["radius_sq"]
+    active = a["inv_radius"] != 0
+    n_rays = 400
+    shown_total = flagged_total = 0
+    for q in range(n_rays):
+        if kind == "far_tiny":
+            # origins hundreds of units away: the discriminant of the 0.05-radius spheres is mostly noise
+            o = (rng.normal(0, 1, 3) * 300).astype(F)
+            target = np.array([rng.uniform(-10, 10), 0.1, rng.uniform(-10, 10)])
+        else:
+            o = np.array([rng.uniform(-12, 12), rng.uniform(0.0, 6), rng.uniform(-12, 12)], F)
+            target = np.array([rng.uniform(-12, 12), rng.uniform(-0.5, 1.0), rng.uniform(-12, 12)])
+        d = (target - o).astype(np.float64)
+        d = (d / np.linalg.norm(d)).astype(F)
+        if q % 7 == 0:
+            d = np.array([0, 0, -1], F) if q % 2 else np.array([1, 0, 0], F)  # axis-parallel: infinite reciprocals
+        flagged = set(np.nonzero(ref_flagged(cx, cy, cz, rsq, o, d) & active)[0].tolist())
+        shown = set(ids[traverse(nodes, o, d)].tolist())
+        assert flagged <= shown, (q, sorted(flagged - shown)[:5])
+        shown_total += len(shown)
+        flagged_total += len(flagged)
+    # and the index is selective (not for far_tiny: from 300 units the reference's own test of a
+    # 0.05-radius sphere is rounding noise and the pad must cover all of it)
+    if kind != "far_tiny":
+        assert shown_total < 0.2 * n_rays * active.sum()
+    assert flagged_total > 0

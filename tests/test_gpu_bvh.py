@@ -100,6 +100,7 @@ def test_bvh_equals_exhaustive_sweep_at_the_baseline_size(renderer, name):
     w, h, spp = 1200, 800, 10
     renderer.set_scene(MAKE[name](w, h))
     a = renderer.render_samples(r1.make_params(w, h, spp, 10001))
+    assert renderer.launch_info()["kernel"] == binding.VARIANT_PREFILTER
     b = renderer.render_samples(r1.make_params(w, h, spp, 10001, variant=BVH))
     assert same(a, b)
 
@@ -212,8 +213,10 @@ def test_bvh_config5_100k_spheres_equals_the_lds_tiled_sweep(renderer):
     w, h, spp = 160, 90, 2
     sc = r1.create_grid_scene(w, h, 400, 250)
     renderer.set_scene(sc)
-    a = renderer.render_samples(r1.make_params(w, h, spp, 5))
-    b = renderer.render_samples(r1.make_params(w, h, spp, 5, variant=BVH))
+    a = renderer.render_samples(r1.make_params(w, h, spp, 5, variant=binding.VARIANT_PREFILTER))
+    assert renderer.launch_info()["kernel"] == binding.VARIANT_PREFILTER
+    b = renderer.render_samples(r1.make_params(w, h, spp, 5))  # DEFAULT resolves to the tree above 1 023 spheres
+    assert renderer.launch_info()["kernel"] == BVH
     assert same(a, b)
     sa = oracle_scene(sc)
     rng = np.random.default_rng(1)

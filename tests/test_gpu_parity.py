@@ -259,12 +259,15 @@ def test_device_resident_shard_and_assemble(renderer):
 
 @pytest.mark.parametrize("gw,gh,w,h,spp", [(64, 40, 160, 120, 4), (33, 31, 96, 64, 3)])
 def test_big_scene_kernels_bit_exact_vs_oracle(renderer, gw, gh, w, h, spp):
-    """> 1023 hittable spheres switches to the 32-bit-index kernels (global attenuation stack)."""
+    """> 1023 hittable spheres: the exhaustive sweep switches to the 32-bit-index kernels (global
+    attenuation stack, LDS-tiled sweep); R1_VARIANT_PREFILTER pins it (DEFAULT resolves to the
+    box tree there, tests/test_gpu_bvh.py)."""
     sc = r1.create_grid_scene(w, h, gw, gh)
     assert int((sc.arrays()["inv_radius"] != 0).sum()) == gw * gh + 4 > 1023
     renderer.set_scene(sc)
-    p = r1.make_params(w, h, spp, 31337)
+    p = r1.make_params(w, h, spp, 31337, variant=binding.VARIANT_PREFILTER)
     img, rays, samples = renderer.render_samples(p)
+    assert renderer.launch_info()["kernel"] == binding.VARIANT_PREFILTER
     oimg, orays, osamples = r1o.render_frame(oracle_scene(sc), oparams(p), want_samples=True)
     assert rays == orays
     assert samples.tobytes() == osamples.tobytes()
@@ -279,7 +282,7 @@ def test_config5_shape_100k_spheres_runs_and_matches_oracle_on_a_crop(renderer):
     w, h, spp = 96, 54, 2
     sc = r1.create_grid_scene(w, h, 400, 250)
     renderer.set_scene(sc)
-    p = r1.make_params(w, h, spp, 5)
+    p = r1.make_params(w, h, spp, 5, variant=binding.VARIANT_PREFILTER)
     img, rays, samples = renderer.render_samples(p)
     sa = oracle_scene(sc)
     rng = np.random.default_rng(0)
@@ -413,6 +416,10 @@ def test_sphere_count_edges_vs_oracle(renderer, n_active):
     p = r1.make_params(w, h, spp, 9)
     img, rays, samples = renderer.render_samples(p)
     assert renderer.launch_info()["spheres_active"] == n_active
+    # DEFAULT = grouped exhaustive sweep up to 1 023 hittable spheres, box tree above
+    assert renderer.launch_info()["kernel"] == (binding.VARIANT_BVH if n_active > 1023 else binding.VARIANT_PREFILTER)
+    sweep = renderer.render_samples(r1.make_params(w, h, spp, 9, variant=binding.VARIANT_PREFILTER))
+    assert sweep[1] == rays and sweep[2].tobytes() == samples.tobytes()
     oimg, orays, osamples = r1o.render_frame(sa, oparams(p), want_samples=True)
     assert rays == orays
     assert samples.tobytes() == osamples.tobytes()
