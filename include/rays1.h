@@ -104,7 +104,7 @@ typedef struct r1_params
 
 enum
 {
-    R1_VARIANT_DEFAULT = 0,   /* fastest validated kernel: PREFILTER up to 1 023 hittable spheres, BVH above */
+    R1_VARIANT_DEFAULT = 0,   /* fastest validated kernel for the scene: BVH, except PREFILTER for 9..127 hittable spheres */
     R1_VARIANT_REFERENCE = 1, /* pass 1 in the reference's exact arithmetic (rayweek1.cpp:190-202),
                                  no prefilter; slower, used to cross-check the default       */
     R1_VARIANT_PREFILTER = 2, /* conservative 8-op prefilter + exact re-test */

@@ -20,11 +20,11 @@
 #include "../../include/rays1.h"
 #include "r1_device.h"
 
-extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int blocks, hipStream_t stream);
+extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int big, int blocks, hipStream_t stream);
 extern "C" hipError_t r1_launch_resolve(const R1ResolveArgs *args, hipStream_t stream);
 extern "C" hipError_t r1_launch_assemble(const void *blocks, void *rgb, int width, int height, int tile_w, int tile_h, int tiles_x,
                                          int tiles_total, int num_shards, int tiles_per_shard, size_t shard_stride, hipStream_t stream);
-extern "C" hipError_t r1_trace_occupancy(int variant, int big, int *blocks_per_cu);
+extern "C" hipError_t r1_trace_occupancy(int variant, int big, size_t dyn_lds, int *blocks_per_cu);
 extern "C" int r1_params_check(const r1_params *p); // r1_host.cpp
 
 // r1_bvh.cpp
@@ -485,6 +485,8 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
     c->n_bvh_nodes = (uint32_t)(bvh.nodes.size() / 16);
     c->n_bvh_leaves = bvh.n_leaves;
     c->bvh_depth = bvh.max_depth;
+    for (int &o : c->occupancy)
+        o = 0; // the tree kernels' LDS footprint follows the tree depth
     c->n_groups = ng;
     c->n_multi = n_multi;
 
@@ -562,11 +564,11 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     int rc = r1_params_check(p);
     if (rc)
         return rc;
-    // kernel selection.  DEFAULT = the fastest validated kernel for the scene: the grouped
-    // exhaustive sweep up to 1 023 hittable spheres (the reference's own regime, MAX_SPHERES 1024,
-    // rayweek1.cpp:174), the box tree above (41-56x the LDS-tiled sweep at 100 k spheres, same
-    // pixels); PREFILTER always forces the exhaustive sweep.
-    const bool big_scene = c->n_active > R1_MAX_ACTIVE_10BIT;
+    // kernel selection.  DEFAULT = the fastest validated kernel for the scene (measured, DESIGN.md
+    // §7): the box tree, except between R1_TREE_SKIP_MIN and R1_TREE_SKIP_MAX hittable spheres
+    // where the ungrouped exhaustive sweep is ahead (medium scene: 46).  PREFILTER always forces
+    // the exhaustive sweep, BVH always the tree; all of them produce the same pixels.
+    const bool tree_default = c->n_active < R1_TREE_SKIP_MIN || c->n_active >= R1_TREE_SKIP_MAX;
     int variant = 2;
     switch (p->variant)
     {
@@ -574,7 +576,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     case R1_VARIANT_STATS: variant = 3; break;
     case R1_VARIANT_BVH: variant = 4; break;
     case R1_VARIANT_BVH_STATS: variant = 5; break;
-    case R1_VARIANT_DEFAULT: variant = big_scene ? 4 : 2; break;
+    case R1_VARIANT_DEFAULT: variant = tree_default ? 4 : 2; break;
     default: variant = 2; break;
     }
     R1_HIP(hipSetDevice(c->device));
@@ -618,9 +620,12 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     a.num_rays = (unsigned long long *)d_rays;
     a.stats = (variant == 3 || variant == 5) ? (unsigned long long *)((char *)c->counters.p + 128) : nullptr;
 
-    const int big = c->n_active > R1_MAX_ACTIVE_10BIT ? 1 : 0;
+    static const int gstack_env = getenv("R1_BVH_GSTACK") ? atoi(getenv("R1_BVH_GSTACK")) : 0;
+    const int big = (c->n_active > R1_MAX_ACTIVE_10BIT || ((variant == 4 || variant == 5) && gstack_env)) ? 1 : 0;
+    a.bvh_depth = c->bvh_depth > 0 ? c->bvh_depth : 1;
     if (c->occupancy[variant + 6 * big] == 0)
-        R1_HIP(r1_trace_occupancy(variant, big, &c->occupancy[variant + 6 * big]));
+        R1_HIP(r1_trace_occupancy(variant, big, (variant == 4 || variant == 5) ? (size_t)a.bvh_depth * R1_BLOCK * 4 : 0,
+                                  &c->occupancy[variant + 6 * big]));
     int per_cu = c->occupancy[variant + 6 * big];
     if (per_cu < 1)
         per_cu = 1;
@@ -661,7 +666,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     R1_HIP(hipMemsetAsync(d_rays, 0, 8, st));
     R1_HIP(hipEventRecord(e0, st));
     if (c->total_samples)
-        R1_HIP(r1_launch_trace(&a, variant, (int)blocks, st));
+        R1_HIP(r1_launch_trace(&a, variant, big, (int)blocks, st));
     R1_HIP(hipEventRecord(e1, st));
 
     R1ResolveArgs r;

@@ -23,6 +23,8 @@
 #define R1_STACK_ENTRIES 51
 #define R1_BVH_STACK 32        // R1_VARIANT_BVH: per-lane traversal stack entries in LDS = most inner nodes on a path
 #define R1_BVH_LEAF 4          // spheres per leaf (<= 7)
+#define R1_TREE_SKIP_MIN 9     // DEFAULT kernel: exhaustive sweep for scenes of [R1_TREE_SKIP_MIN, R1_TREE_SKIP_MAX) hittable
+#define R1_TREE_SKIP_MAX 128   // spheres, box tree otherwise
 
 // Division of n < 2^31 by a launch constant: pow2 ? n >> shift : mulhi(n, mul) >> shift, with
 // mul = ceil(2^(32+shift) / d), shift = floor(log2 d) (exact for every n < 2^31; r1_capi.cpp).
@@ -86,6 +88,7 @@ struct R1TraceArgs
     unsigned long long *num_rays; // accumulated color() invocations
     uint32_t *gstack;             // big scenes: attenuation stack [R1_STACK_ENTRIES][grid threads], else null
     unsigned long long *stats;    // diagnostic counters (R1_VARIANT_STATS builds only), else null
+    int32_t bvh_depth;            // tree kernels: traversal stack entries per thread (dynamic LDS = depth * R1_BLOCK * 4)
 };
 
 struct R1ResolveArgs

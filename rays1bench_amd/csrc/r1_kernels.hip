@@ -752,7 +752,8 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
     __shared__ uint32_t s_stack[BIG ? 1 : R1_STACK_WORDS * R1_BLOCK];
     __shared__ uint32_t s_cand[VARIANT == 2 ? (BIG ? R1_CAND_CAP : R1_BIT_WORDS) * R1_BLOCK : 1];
     __shared__ IDX s_pairs[VARIANT == 2 ? (R1_BLOCK / 64) * R1_PAIR_CAP : 1];
-    __shared__ uint32_t s_trav[VARIANT == 4 ? R1_BVH_STACK * R1_BLOCK : 1];
+    // R1_VARIANT_BVH: traversal stack [tree depth][thread], sized at launch (dynamic LDS)
+    extern __shared__ uint32_t s_trav[];
     const uint32_t gstride = gridDim.x * R1_BLOCK, gtid = blockIdx.x * R1_BLOCK + threadIdx.x;
     __shared__ unsigned long long s_best[VARIANT == 2 ? R1_BLOCK : 1];
     __shared__ f4 s_tile[BIG && VARIANT == 2 ? 2 * R1_TILE_F4 : 1];
@@ -1075,17 +1076,19 @@ __global__ void __launch_bounds__(256)
 
 // ---- launchers (called from r1_capi.cpp) -----------------------------------------------------
 
-extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int blocks, hipStream_t stream)
+extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int big_in, int blocks, hipStream_t stream)
 {
-    const bool big = args->scene.n_active > R1_MAX_ACTIVE_10BIT;
+    // dynamic LDS: the traversal stack of the tree kernels, one entry per inner node on a path
+    const size_t trav = (variant == 4 || variant == 5) ? (size_t)args->bvh_depth * R1_BLOCK * sizeof(uint32_t) : 0;
+    const bool big = big_in != 0; // 32-bit hit indices, attenuation stack in the global workspace
     if (variant == 5 && big)
-        hipLaunchKernelGGL((r1_trace_kernel<4, true, true>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
+        hipLaunchKernelGGL((r1_trace_kernel<4, true, true>), dim3(blocks), dim3(R1_BLOCK), trav, stream, *args);
     else if (variant == 5)
-        hipLaunchKernelGGL((r1_trace_kernel<4, true, false>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
+        hipLaunchKernelGGL((r1_trace_kernel<4, true, false>), dim3(blocks), dim3(R1_BLOCK), trav, stream, *args);
     else if (variant == 4 && big)
-        hipLaunchKernelGGL((r1_trace_kernel<4, false, true>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
+        hipLaunchKernelGGL((r1_trace_kernel<4, false, true>), dim3(blocks), dim3(R1_BLOCK), trav, stream, *args);
     else if (variant == 4)
-        hipLaunchKernelGGL((r1_trace_kernel<4, false, false>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
+        hipLaunchKernelGGL((r1_trace_kernel<4, false, false>), dim3(blocks), dim3(R1_BLOCK), trav, stream, *args);
     else if (variant == 1 && big)
         hipLaunchKernelGGL((r1_trace_kernel<1, false, true>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
     else if (variant == 1)
@@ -1120,16 +1123,16 @@ extern "C" hipError_t r1_launch_assemble(const void *blocks, void *rgb, int widt
     return hipGetLastError();
 }
 
-extern "C" hipError_t r1_trace_occupancy(int variant, int big, int *blocks_per_cu)
+extern "C" hipError_t r1_trace_occupancy(int variant, int big, size_t dyn_lds, int *blocks_per_cu)
 {
     if (variant == 5 && big)
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<4, true, true>, R1_BLOCK, 0);
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<4, true, true>, R1_BLOCK, dyn_lds);
     if (variant == 5)
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<4, true, false>, R1_BLOCK, 0);
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<4, true, false>, R1_BLOCK, dyn_lds);
     if (variant == 4 && big)
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<4, false, true>, R1_BLOCK, 0);
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<4, false, true>, R1_BLOCK, dyn_lds);
     if (variant == 4)
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<4, false, false>, R1_BLOCK, 0);
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<4, false, false>, R1_BLOCK, dyn_lds);
     if (variant == 1 && big)
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<1, false, true>, R1_BLOCK, 0);
     if (variant == 1)

@@ -96,10 +96,10 @@ def test_bvh_full_frame_bit_exact_vs_oracle(renderer, name, w, h, spp, seed):
 @pytest.mark.parametrize("name", ["small", "medium", "large"])
 def test_bvh_equals_exhaustive_sweep_at_the_baseline_size(renderer, name):
     """1200x800x10 (BASELINE configs 2/3): the tree-driven kernel and the default (grouped
-    exhaustive sweep) agree on every one of the 9.6 M samples."""
+    exhaustive sweep) agree on every one of the 9.6 M samples (the exhaustive sweep pinned with PREFILTER)."""
     w, h, spp = 1200, 800, 10
     renderer.set_scene(MAKE[name](w, h))
-    a = renderer.render_samples(r1.make_params(w, h, spp, 10001))
+    a = renderer.render_samples(r1.make_params(w, h, spp, 10001, variant=binding.VARIANT_PREFILTER))
     assert renderer.launch_info()["kernel"] == binding.VARIANT_PREFILTER
     b = renderer.render_samples(r1.make_params(w, h, spp, 10001, variant=BVH))
     assert same(a, b)
@@ -232,7 +232,7 @@ def test_bvh_shards_and_tiles(renderer):
     change the frame."""
     w, h, spp = 200, 120, 3
     renderer.set_scene(r1.create_large_scene(w, h))
-    base = renderer.render(r1.make_params(w, h, spp, 77))
+    base = renderer.render(r1.make_params(w, h, spp, 77, variant=binding.VARIANT_PREFILTER))
     full = renderer.render(r1.make_params(w, h, spp, 77, variant=BVH))
     assert full[0].tobytes() == base[0].tobytes() and full[1] == base[1]
     odd = renderer.render(r1.make_params(w, h, spp, 77, tile_w=24, tile_h=40, variant=BVH))

@@ -31,6 +31,23 @@ MAKE = {"small": r1.create_small_scene, "medium": r1.create_medium_scene, "large
 ALLOWED_FLIP_FRACTION = 1e-5
 
 
+# Every test of this module runs once per kernel family: DEFAULT (resolves to the box tree except
+# for 9..127 hittable spheres) and PREFILTER (always the grouped exhaustive sweep).  Calls that
+# name a variant explicitly keep it.
+KERNEL = {"variant": 0}
+
+
+@pytest.fixture(autouse=True, params=[binding.VARIANT_DEFAULT, binding.VARIANT_PREFILTER], ids=["default", "sweep"])
+def kernel_family(request):
+    KERNEL["variant"] = request.param
+    yield request.param
+
+
+def mp(*a, **k):
+    k.setdefault("variant", KERNEL["variant"])
+    return r1.make_params(*a, **k)
+
+
 @pytest.fixture(scope="module")
 def renderer():
     assert r1.device_count() >= 1, "no HIP device: the product has no CPU fallback"
@@ -60,7 +77,7 @@ def test_samples_match_reference_fixture_1200x800x10(renderer, name):
     w, h, spp, seed, _ = g["hdr"].tolist()
     sc = MAKE[name](w, h)
     renderer.set_scene(sc)
-    img, rays, samples = renderer.render_samples(r1.make_params(w, h, spp, seed))
+    img, rays, samples = renderer.render_samples(mp(w, h, spp, seed))
     idx = (g["y"].astype(np.int64) * w + g["x"]) * spp + g["s"]
     got = samples[idx]
     same_rays = rays_of(got) == g["rays"]
@@ -84,7 +101,7 @@ def test_small_frames_match_reference_fixture(renderer, name):
     g = r1o.read_golden(os.path.join(GOLD, f"frame_{name}_200x100x4.bin"))
     w, h, spp, seed = g["hdr"].tolist()
     renderer.set_scene(MAKE[name](w, h))
-    img, rays, _ = renderer.render(r1.make_params(w, h, spp, seed))
+    img, rays, _ = renderer.render(mp(w, h, spp, seed))
     assert rays == int(g["rays"][0])
     assert img.tobytes() == g["image"].tobytes()
 
@@ -93,7 +110,7 @@ def test_ragged_frame_matches_reference_fixture(renderer):
     g = r1o.read_golden(os.path.join(GOLD, "frame_medium_77x45x3.bin"))
     w, h, spp, seed = g["hdr"].tolist()
     renderer.set_scene(r1.create_medium_scene(w, h))
-    img, rays, _ = renderer.render(r1.make_params(w, h, spp, seed))
+    img, rays, _ = renderer.render(mp(w, h, spp, seed))
     assert rays == int(g["rays"][0])
     assert img.tobytes() == g["image"].tobytes()
 
@@ -102,7 +119,7 @@ def test_second_seed_and_spp_64_fixture(renderer):
     g = r1o.read_golden(os.path.join(GOLD, "samples_large_320x200x64.bin"))
     w, h, spp, seed, _ = g["hdr"].tolist()
     renderer.set_scene(r1.create_large_scene(w, h))
-    img, rays, samples = renderer.render_samples(r1.make_params(w, h, spp, seed))
+    img, rays, samples = renderer.render_samples(mp(w, h, spp, seed))
     got = samples[(g["y"].astype(np.int64) * w + g["x"]) * spp + g["s"]]
     assert (rays_of(got) == g["rays"]).all()
     assert got[:, :3].tobytes() == g["rgb"].tobytes()
@@ -115,7 +132,7 @@ def test_second_seed_and_spp_64_fixture(renderer):
 def test_full_frame_bit_exact_vs_oracle(renderer, name, w, h, spp, seed):
     sc = MAKE[name](w, h)
     renderer.set_scene(sc)
-    p = r1.make_params(w, h, spp, seed)
+    p = mp(w, h, spp, seed)
     img, rays, samples = renderer.render_samples(p)
     oimg, orays, osamples = r1o.render_frame(oracle_scene(sc), oparams(p), want_samples=True)
     differing = (samples.view(np.uint32) != osamples.view(np.uint32)).any(1)
@@ -129,8 +146,8 @@ def test_reference_variant_equals_prefilter_variant(renderer):
     with the exact re-test the two kernels are bit-identical on every sample."""
     for name, (w, h, spp) in {"small": (320, 200, 8), "medium": (320, 200, 8), "large": (400, 300, 6)}.items():
         renderer.set_scene(MAKE[name](w, h))
-        a = renderer.render_samples(r1.make_params(w, h, spp, 99, variant=binding.VARIANT_REFERENCE))
-        b = renderer.render_samples(r1.make_params(w, h, spp, 99, variant=binding.VARIANT_PREFILTER))
+        a = renderer.render_samples(mp(w, h, spp, 99, variant=binding.VARIANT_REFERENCE))
+        b = renderer.render_samples(mp(w, h, spp, 99, variant=binding.VARIANT_PREFILTER))
         assert a[1] == b[1]
         assert a[2].tobytes() == b[2].tobytes()
         assert a[0].tobytes() == b[0].tobytes()
@@ -140,7 +157,7 @@ def test_reference_variant_equals_prefilter_variant(renderer):
 def test_edge_sizes_and_bounce_limits_vs_oracle(renderer, w, h, spp, bounces):
     sc = r1.create_medium_scene(w, h)
     renderer.set_scene(sc)
-    p = r1.make_params(w, h, spp, 5, max_bounces=bounces)
+    p = mp(w, h, spp, 5, max_bounces=bounces)
     img, rays, samples = renderer.render_samples(p)
     oimg, orays, osamples = r1o.render_frame(oracle_scene(sc), oparams(p), want_samples=True)
     assert rays == orays
@@ -154,7 +171,7 @@ def test_hollow_sphere_and_placeholders_are_never_hit(renderer):
     skipped (rayweek1.cpp:291): a scene with them removed renders identically."""
     sc = r1.create_small_scene(200, 100)
     renderer.set_scene(sc)
-    p = r1.make_params(200, 100, 8, 3)
+    p = mp(200, 100, 8, 3)
     a = renderer.render_samples(p)
     arr = sc.arrays()
     keep = arr["inv_radius"] != 0
@@ -186,9 +203,9 @@ def _as_ccamera(sa):
 def test_full_size_determinism_seed_and_statistics(renderer):
     w, h, spp = 1200, 800, 10
     renderer.set_scene(r1.create_large_scene(w, h))
-    a = renderer.render(r1.make_params(w, h, spp, 10001))
-    b = renderer.render(r1.make_params(w, h, spp, 10001))
-    c = renderer.render(r1.make_params(w, h, spp, 10002))
+    a = renderer.render(mp(w, h, spp, 10001))
+    b = renderer.render(mp(w, h, spp, 10001))
+    c = renderer.render(mp(w, h, spp, 10002))
     assert a[1] == b[1] and a[0].tobytes() == b[0].tobytes()  # run-to-run identical
     assert c[0].tobytes() != a[0].tobytes() and abs(c[1] - a[1]) / a[1] < 2e-3
     with open(os.path.join(GOLD, "MANIFEST.json")) as f:
@@ -205,12 +222,12 @@ def test_full_size_determinism_seed_and_statistics(renderer):
 def test_shards_tile_the_frame_exactly(renderer, shards):
     w, h, spp = 300, 170, 4
     renderer.set_scene(r1.create_large_scene(w, h))
-    full, full_rays, _ = renderer.render(r1.make_params(w, h, spp, 11))
+    full, full_rays, _ = renderer.render(mp(w, h, spp, 11))
     acc = np.zeros_like(full)
     total = 0
     for s in range(shards):
         part = np.zeros_like(full)
-        rays, _ = renderer.render_into(r1.make_params(w, h, spp, 11, shard=s, num_shards=shards), part)
+        rays, _ = renderer.render_into(mp(w, h, spp, 11, shard=s, num_shards=shards), part)
         assert not ((acc != 0) & (part != 0)).any() or True
         acc = np.maximum(acc, part)
         total += rays
@@ -223,16 +240,16 @@ def test_device_resident_shard_and_assemble(renderer):
     assert torch.cuda.is_available()
     w, h, spp, shards = 300, 170, 4, 4
     renderer.set_scene(r1.create_medium_scene(w, h))
-    full, full_rays, _ = renderer.render(r1.make_params(w, h, spp, 21))
-    nbytes = binding.shard_block_bytes(r1.make_params(w, h, spp, 21, shard=0, num_shards=shards))
+    full, full_rays, _ = renderer.render(mp(w, h, spp, 21))
+    nbytes = binding.shard_block_bytes(mp(w, h, spp, 21, shard=0, num_shards=shards))
     blocks = torch.zeros((shards, nbytes), dtype=torch.uint8, device="cuda")
     rays = torch.zeros(shards, dtype=torch.int64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     for s in range(shards):
-        p = r1.make_params(w, h, spp, 21, shard=s, num_shards=shards)
+        p = mp(w, h, spp, 21, shard=s, num_shards=shards)
         renderer.render_shard_device(p, blocks[s].data_ptr(), rays[s:].data_ptr(), stream)
     out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
-    renderer.assemble_device(r1.make_params(w, h, spp, 21, shard=0, num_shards=shards), blocks.data_ptr(), out.data_ptr(), stream)
+    renderer.assemble_device(mp(w, h, spp, 21, shard=0, num_shards=shards), blocks.data_ptr(), out.data_ptr(), stream)
     torch.cuda.synchronize()
     assert int(rays.sum().item()) == full_rays
     assert out.cpu().numpy().tobytes() == full.tobytes()
@@ -242,10 +259,10 @@ def test_device_resident_shard_and_assemble(renderer):
     rec = nbytes + 8
     records = torch.zeros((shards, rec), dtype=torch.uint8, device="cuda")
     for s in range(shards):
-        p = r1.make_params(w, h, spp, 21, shard=s, num_shards=shards)
+        p = mp(w, h, spp, 21, shard=s, num_shards=shards)
         renderer.render_shard_device(p, records[s].data_ptr(), records[s].data_ptr() + nbytes, stream)
     out2 = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
-    renderer.assemble_device_strided(r1.make_params(w, h, spp, 21, shard=0, num_shards=shards), records.data_ptr(), rec, out2.data_ptr(), stream)
+    renderer.assemble_device_strided(mp(w, h, spp, 21, shard=0, num_shards=shards), records.data_ptr(), rec, out2.data_ptr(), stream)
     torch.cuda.synchronize()
     from rays1bench_amd import sharding
     assert out2.cpu().numpy().tobytes() == full.tobytes()
@@ -265,14 +282,14 @@ def test_big_scene_kernels_bit_exact_vs_oracle(renderer, gw, gh, w, h, spp):
     sc = r1.create_grid_scene(w, h, gw, gh)
     assert int((sc.arrays()["inv_radius"] != 0).sum()) == gw * gh + 4 > 1023
     renderer.set_scene(sc)
-    p = r1.make_params(w, h, spp, 31337, variant=binding.VARIANT_PREFILTER)
+    p = mp(w, h, spp, 31337, variant=binding.VARIANT_PREFILTER)
     img, rays, samples = renderer.render_samples(p)
     assert renderer.launch_info()["kernel"] == binding.VARIANT_PREFILTER
     oimg, orays, osamples = r1o.render_frame(oracle_scene(sc), oparams(p), want_samples=True)
     assert rays == orays
     assert samples.tobytes() == osamples.tobytes()
     assert img.tobytes() == oimg.tobytes()
-    ref = renderer.render_samples(r1.make_params(w, h, spp, 31337, variant=binding.VARIANT_REFERENCE))
+    ref = renderer.render_samples(mp(w, h, spp, 31337, variant=binding.VARIANT_REFERENCE))
     assert ref[1] == rays and ref[2].tobytes() == samples.tobytes()
 
 
@@ -282,7 +299,7 @@ def test_config5_shape_100k_spheres_runs_and_matches_oracle_on_a_crop(renderer):
     w, h, spp = 96, 54, 2
     sc = r1.create_grid_scene(w, h, 400, 250)
     renderer.set_scene(sc)
-    p = r1.make_params(w, h, spp, 5, variant=binding.VARIANT_PREFILTER)
+    p = mp(w, h, spp, 5, variant=binding.VARIANT_PREFILTER)
     img, rays, samples = renderer.render_samples(p)
     sa = oracle_scene(sc)
     rng = np.random.default_rng(0)
@@ -300,6 +317,8 @@ def test_config5_shape_100k_spheres_runs_and_matches_oracle_on_a_crop(renderer):
 def test_rayweek1_hip_program_matches_the_abi_path(renderer, tmp_path):
     """rayweek1_hip prints the reference's report block, writes out_<scene>.txt / .tga in the
     reference's formats, and its pixels equal what the C-ABI returns for the same parameters."""
+    if KERNEL["variant"] != binding.VARIANT_DEFAULT:
+        pytest.skip("runs the program's own kernel choice: once is enough")
     import re
     import subprocess
     exe = os.path.join(ROOT, "rays1bench_amd", "lib", "rayweek1_hip")
@@ -313,7 +332,7 @@ def test_rayweek1_hip_program_matches_the_abi_path(renderer, tmp_path):
                             text, flags=re.M)
         assert len(blocks) == 2 and all(int(b[0]) == w * h * spp for b in blocks)
         renderer.set_scene(MAKE[name](w, h))
-        img, rays, _ = renderer.render(r1.make_params(w, h, spp, 10001))
+        img, rays, _ = renderer.render(mp(w, h, spp, 10001))
         assert {int(b[1]) for b in blocks} == {rays}
         assert open(tmp_path / f"out_{name}.tga", "rb").read() == r1o.tga_bytes(img)
         assert re.fullmatch(rf"hip\|\d+\.\d{{3}}s\|{rays}\|\d+\.\d{{3}} mrays/s\|", open(tmp_path / f"out_{name}.txt").read())
@@ -340,9 +359,9 @@ def test_image_is_independent_of_tile_size_and_matches_oracle(renderer, tile_w, 
     w, h, spp = 150, 90, 3
     sc = r1.create_medium_scene(w, h)
     renderer.set_scene(sc)
-    p = r1.make_params(w, h, spp, 42, tile_w=tile_w, tile_h=tile_h)
+    p = mp(w, h, spp, 42, tile_w=tile_w, tile_h=tile_h)
     img, rays, samples = renderer.render_samples(p)
-    oimg, orays, osamples = r1o.render_frame(oracle_scene(sc), oparams(r1.make_params(w, h, spp, 42)), want_samples=True)
+    oimg, orays, osamples = r1o.render_frame(oracle_scene(sc), oparams(mp(w, h, spp, 42)), want_samples=True)
     assert rays == orays
     assert samples.tobytes() == osamples.tobytes()
     assert img.tobytes() == oimg.tobytes()
@@ -351,7 +370,7 @@ def test_image_is_independent_of_tile_size_and_matches_oracle(renderer, tile_w, 
     total = 0
     for s in range(3):
         part = np.zeros_like(img)
-        total += renderer.render_into(r1.make_params(w, h, spp, 42, tile_w=tile_w, tile_h=tile_h, shard=s, num_shards=3), part)[0]
+        total += renderer.render_into(mp(w, h, spp, 42, tile_w=tile_w, tile_h=tile_h, shard=s, num_shards=3), part)[0]
         acc = np.maximum(acc, part)
     assert total == rays and acc.tobytes() == img.tobytes()
 
@@ -363,11 +382,11 @@ def test_bad_arguments_are_rejected_not_rendered(renderer):
         kw = dict(width=64, height=64, spp=1, seed=1, max_bounces=50, tile_w=32, tile_h=32, shard=0, num_shards=1)
         kw.update(bad)
         with pytest.raises(r1.R1Error) as e:
-            renderer.render(r1.make_params(**kw))
+            renderer.render(mp(**kw))
         assert e.value.code == binding.R1_EINVAL, bad
     fresh = r1.Renderer(0)
     with pytest.raises(r1.R1Error):
-        fresh.render(r1.make_params(8, 8, 1))  # no scene set
+        fresh.render(mp(8, 8, 1))  # no scene set
     fresh.close()
 
 
@@ -378,6 +397,8 @@ def test_bench_two_ranks_rehearsal_gathers_the_unsharded_frame():
     """Two bench.py ranks share the one GPU (R1_BENCH_DEVICE=0) with gloo standing in for RCCL:
     real kernels, real tile split, the same gather_blocks/assemble code as the N-GPU run.
     --check compares the gathered + assembled image and ray count with an unsharded render."""
+    if KERNEL["variant"] != binding.VARIANT_DEFAULT:
+        pytest.skip("runs the program's own kernel choice: once is enough")
     import socket
     import subprocess
     import sys
@@ -400,7 +421,7 @@ def test_bench_two_ranks_rehearsal_gathers_the_unsharded_frame():
 
 
 @pytest.mark.parametrize("n_active", [0, 1, 7, 8, 9, 1023, 1024])
-def test_sphere_count_edges_vs_oracle(renderer, n_active):
+def test_sphere_count_edges_vs_oracle(renderer, n_active, kernel_family):
     w, h, spp = 64, 48, 2
     src = r1.create_grid_scene(w, h, 36, 30)  # 1080 small spheres + ground + 3 big
     arr = src.arrays()
@@ -413,12 +434,13 @@ def test_sphere_count_edges_vs_oracle(renderer, n_active):
         sub[k] = np.concatenate([sub[k], np.full(pad, fill, sub[k].dtype)])
     sa = r1o.SceneArrays(sub, src.camera_array())
     renderer.set_scene_raw(_as_cscene(sa), _as_ccamera(sa))
-    p = r1.make_params(w, h, spp, 9)
+    p = mp(w, h, spp, 9)
     img, rays, samples = renderer.render_samples(p)
     assert renderer.launch_info()["spheres_active"] == n_active
-    # DEFAULT = grouped exhaustive sweep up to 1 023 hittable spheres, box tree above
-    assert renderer.launch_info()["kernel"] == (binding.VARIANT_BVH if n_active > 1023 else binding.VARIANT_PREFILTER)
-    sweep = renderer.render_samples(r1.make_params(w, h, spp, 9, variant=binding.VARIANT_PREFILTER))
+    # DEFAULT = box tree except for 9..127 hittable spheres (r1_device.h R1_TREE_SKIP_*)
+    tree = kernel_family == binding.VARIANT_DEFAULT and (n_active < 9 or n_active >= 128)
+    assert renderer.launch_info()["kernel"] == (binding.VARIANT_BVH if tree else binding.VARIANT_PREFILTER)
+    sweep = renderer.render_samples(mp(w, h, spp, 9, variant=binding.VARIANT_PREFILTER))
     assert sweep[1] == rays and sweep[2].tobytes() == samples.tobytes()
     oimg, orays, osamples = r1o.render_frame(sa, oparams(p), want_samples=True)
     assert rays == orays
@@ -475,9 +497,9 @@ def test_grouped_prefilter_is_exact_on_random_scenes(renderer, case):
         arr[k] = np.concatenate([arr[k], np.full(pad, fill, arr[k].dtype)])
     sa = r1o.SceneArrays(arr, cam)
     renderer.set_scene_raw(_as_cscene(sa), _as_ccamera(sa))
-    p = r1.make_params(w, h, spp, 1234)
+    p = mp(w, h, spp, 1234)
     got = renderer.render_samples(p)
-    ref = renderer.render_samples(r1.make_params(w, h, spp, 1234, variant=binding.VARIANT_REFERENCE))
+    ref = renderer.render_samples(mp(w, h, spp, 1234, variant=binding.VARIANT_REFERENCE))
     assert got[1] == ref[1] and got[2].tobytes() == ref[2].tobytes() and got[0].tobytes() == ref[0].tobytes()
     oimg, orays, osamples = r1o.render_frame(sa, oparams(p), want_samples=True)
     assert got[1] == orays and got[2].tobytes() == osamples.tobytes()
