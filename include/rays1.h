@@ -226,13 +226,15 @@ int r1_last_launch_info(r1_context *ctx, r1_launch_info *out);
 
 /* Shape of the spatial index R1_VARIANT_BVH uses (r1_bvh.cpp; the reference has no such
  * structure, README.md:163).  Builds it on the host exactly as r1_set_scene does.  Optional
- * outputs: `nodes_out` receives 16 floats per inner node {m0.xyz, w2 | e0.xyz, k | m1.xyz,
- * child0 | e1.xyz, child1} (child: bit 31 = leaf, bits 28..30 sphere count, bits 0..27 first
- * leaf slot; else inner node index), `ids_out[slot]` the scene index of the sphere in each
- * leaf slot.  leaf_max <= 0 selects the build's default. */
+ * outputs: `nodes_out` receives 16 floats per inner node {m0x m1x m0y m1y | m0z m1z e0x e1x |
+ * e0y e1y e0z e1z | w2 k child0 child1} (child i: box centre m_i, half extent e_i; reference:
+ * bit 31 = leaf, then bits 28..30 = number of sphere PAIRS and bits 0..27 the first pair; else
+ * inner node index), `ids_out[2 * pair + {0, 1}]` the scene index of each leaf sphere
+ * (0xFFFFFFFF = the empty partner of an odd sphere); needs 2 * info.pairs entries.
+ * leaf_max <= 0 selects the build's default spheres per leaf. */
 typedef struct r1_bvh_info
 {
-    int32_t nodes, leaves, depth, stack_entries, spheres;
+    int32_t nodes, leaves, depth, stack_entries, spheres, pairs;
 } r1_bvh_info;
 int r1_bvh_describe(const r1_scene *scene, int32_t leaf_max, r1_bvh_info *info, float *nodes_out, size_t nodes_cap, uint32_t *ids_out,
                     size_t ids_cap);

@@ -53,7 +53,8 @@ class LaunchInfo(C.Structure):
 
 
 class BvhInfo(C.Structure):
-    _fields_ = [("nodes", C.c_int32), ("leaves", C.c_int32), ("depth", C.c_int32), ("stack_entries", C.c_int32), ("spheres", C.c_int32)]
+    _fields_ = [("nodes", C.c_int32), ("leaves", C.c_int32), ("depth", C.c_int32), ("stack_entries", C.c_int32), ("spheres", C.c_int32),
+                ("pairs", C.c_int32)]
 
 
 def make_params(width, height, spp, seed=10001, max_bounces=50, tile_w=32, tile_h=32, shard=0, num_shards=1, variant=0):
@@ -288,14 +289,14 @@ def tile_count(params):
 
 
 def bvh_describe(cscene, leaf_max=0):
-    """Host-side build of the R1_VARIANT_BVH index: (info dict, nodes float32[n,16], ids uint32[spheres])."""
+    """Host-side build of the R1_VARIANT_BVH index: (info dict, nodes float32[n,16], ids uint32[2*pairs], 0xFFFFFFFF = empty slot)."""
     info = BvhInfo()
     _check(lib().r1_bvh_describe(C.byref(cscene), leaf_max, C.byref(info), None, 0, None, 0))
     nodes = np.zeros((info.nodes, 16), np.float32)
-    ids = np.zeros(max(info.spheres, 1), np.uint32)
+    ids = np.zeros(max(2 * info.pairs, 2), np.uint32)
     _check(lib().r1_bvh_describe(C.byref(cscene), leaf_max, C.byref(info), nodes.ctypes.data_as(_f32p), nodes.size,
                                  ids.ctypes.data_as(C.POINTER(C.c_uint32)), ids.size))
-    return {k: int(getattr(info, k)) for k, _ in BvhInfo._fields_}, nodes, ids[:info.spheres]
+    return {k: int(getattr(info, k)) for k, _ in BvhInfo._fields_}, nodes, ids[:2 * info.pairs]
 
 
 class RESULT:

@@ -34,8 +34,8 @@
 struct R1Bvh
 {
     std::vector<float> nodes;   // 16 floats per node, see R1DeviceScene::bvh_nodes
-    std::vector<float> prims;   // leaf order: {cx, cy, cz, radius_sq}
-    std::vector<uint32_t> ids;  // leaf order: active index
+    std::vector<float> prims;   // leaf order, 8 floats per PAIR of spheres: {cx_a cx_b cy_a cy_b cz_a cz_b rsq_a rsq_b}
+    std::vector<uint32_t> ids;  // 2 per pair: active index, 0xFFFFFFFF for the partner of an odd sphere
     int max_depth = 0;          // inner nodes on the longest root-to-leaf path
     uint32_t n_leaves = 0;
 };
@@ -117,15 +117,24 @@ struct Builder
 
     uint32_t make_leaf(uint32_t b, uint32_t e)
     {
-        const uint32_t first = (uint32_t)out->ids.size();
-        for (uint32_t i = b; i < e; ++i)
+        // spheres are stored in PAIRS (the kernel tests two per packed instruction); the partner of
+        // an odd sphere has radius_sq = -inf, which makes its discriminant -inf: never flagged
+        const uint32_t first = (uint32_t)(out->ids.size() / 2);
+        const uint32_t pairs = (e - b + 1) / 2;
+        for (uint32_t q = 0; q < pairs; ++q)
         {
-            const uint32_t a = order[i];
-            out->prims.push_back(cx[a]), out->prims.push_back(cy[a]), out->prims.push_back(cz[a]), out->prims.push_back(rsq[a]);
-            out->ids.push_back(a);
+            const uint32_t ia = order[b + 2 * q];
+            const bool has_b = b + 2 * q + 1 < e;
+            const uint32_t ib = has_b ? order[b + 2 * q + 1] : ia;
+            const float pad_r = -INFINITY;
+            const float v[8] = {cx[ia], has_b ? cx[ib] : 0.0f, cy[ia], has_b ? cy[ib] : 0.0f,
+                                cz[ia], has_b ? cz[ib] : 0.0f, rsq[ia], has_b ? rsq[ib] : pad_r};
+            out->prims.insert(out->prims.end(), v, v + 8);
+            out->ids.push_back(ia);
+            out->ids.push_back(has_b ? ib : 0xFFFFFFFFu);
         }
         ++out->n_leaves;
-        return LEAF | ((e - b) << 28) | first;
+        return LEAF | (pairs << 28) | first;
     }
 
     // returns the child reference for order[b, e); bx = its bounds
@@ -239,11 +248,12 @@ struct Builder
         encode(b1, m1, e1, w1, k1);
         float *p = &out->nodes[16 * (size_t)node];
         const float w2 = round_up(std::max(w0, w1)), k = round_up(std::max(k0, k1));
-        p[0] = m0[0], p[1] = m0[1], p[2] = m0[2], p[3] = w2;
-        p[4] = e0[0], p[5] = e0[1], p[6] = e0[2], p[7] = k;
-        p[8] = m1[0], p[9] = m1[1], p[10] = m1[2];
-        p[12] = e1[0], p[13] = e1[1], p[14] = e1[2];
-        memcpy(&p[11], &c0, 4);
+        // {m0x m1x m0y m1y} {m0z m1z e0x e1x} {e0y e1y e0z e1z} {w2 k child0 child1}
+        p[0] = m0[0], p[1] = m1[0], p[2] = m0[1], p[3] = m1[1];
+        p[4] = m0[2], p[5] = m1[2], p[6] = e0[0], p[7] = e1[0];
+        p[8] = e0[1], p[9] = e1[1], p[10] = e0[2], p[11] = e1[2];
+        p[12] = w2, p[13] = k;
+        memcpy(&p[14], &c0, 4);
         memcpy(&p[15], &c1, 4);
     }
 };
@@ -258,8 +268,8 @@ void r1_build_bvh(uint32_t na, const float *cx, const float *cy, const float *cz
     out.max_depth = 0, out.n_leaves = 0;
     if (leaf_max < 1)
         leaf_max = 1;
-    if (leaf_max > 7)
-        leaf_max = 7;
+    if (leaf_max > 14)
+        leaf_max = 14; // 7 pairs
     Builder B;
     B.cx = cx, B.cy = cy, B.cz = cz, B.rsq = rsq;
     B.out = &out;
@@ -294,7 +304,7 @@ void r1_build_bvh(uint32_t na, const float *cx, const float *cy, const float *cz
         // one child only: the other never passes (half extent -inf) and is an empty leaf anyway
         B.fill(0, b0, c0, b0, c1);
         float *p = &out.nodes[0];
-        p[12] = p[13] = p[14] = -INFINITY;
+        p[7] = p[9] = p[11] = -INFINITY;
     };
     const uint32_t EMPTY_LEAF = Builder::LEAF; // count 0
     if (na == 0)
@@ -305,7 +315,7 @@ void r1_build_bvh(uint32_t na, const float *cx, const float *cy, const float *cz
             z.lo[k] = z.hi[k] = z.clo[k] = z.chi[k] = 0;
         fill_root_with(z, EMPTY_LEAF, nullptr, EMPTY_LEAF);
         float *p = &out.nodes[0];
-        p[4] = p[5] = p[6] = -INFINITY;
+        p[6] = p[8] = p[10] = -INFINITY;
         out.max_depth = 1;
     }
     else if (na <= (uint32_t)leaf_max)
@@ -323,9 +333,9 @@ void r1_build_bvh(uint32_t na, const float *cx, const float *cy, const float *cz
         const uint32_t root = B.build(0, na, 0, all);
         (void)root; // == 0
     }
-    // keep the prim table non-empty and 16-byte padded for the loader
+    // keep the tables non-empty for the uploader
     if (out.prims.empty())
-        out.prims.assign(4, 0.0f), out.ids.assign(1, 0u);
+        out.prims.assign(8, 0.0f), out.ids.assign(2, 0xFFFFFFFFu);
 }
 
 // Host-only view of the index (include/rays1.h): what r1_set_scene would build for this scene.
@@ -358,12 +368,13 @@ extern "C" int r1_bvh_describe(const r1_scene *s, int32_t leaf_max, r1_bvh_info 
             return R1_ELIMIT;
         memcpy(nodes_out, b.nodes.data(), b.nodes.size() * 4);
     }
+    info->pairs = (int32_t)(b.ids.size() / 2);
     if (ids_out)
     {
-        if (ids_cap < na)
+        if (ids_cap < b.ids.size())
             return R1_ELIMIT;
-        for (uint32_t i = 0; i < na; ++i)
-            ids_out[i] = scene_index[b.ids[i]]; // leaf slot -> index into the caller's scene arrays
+        for (size_t i = 0; i < b.ids.size(); ++i) // leaf slot (2 per pair) -> index into the caller's scene arrays
+            ids_out[i] = b.ids[i] == 0xFFFFFFFFu || na == 0 ? 0xFFFFFFFFu : scene_index[b.ids[i]];
     }
     return R1_OK;
 }

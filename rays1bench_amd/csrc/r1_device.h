@@ -22,7 +22,7 @@
 #define R1_MAX_ACTIVE (1u << 21) // big-scene kernels: 26-bit pair indices, limit kept at 2 M spheres
 #define R1_STACK_ENTRIES 51
 #define R1_BVH_STACK 32        // R1_VARIANT_BVH: per-lane traversal stack entries in LDS = most inner nodes on a path
-#define R1_BVH_LEAF 4          // spheres per leaf (<= 7)
+#define R1_BVH_LEAF 4          // spheres per leaf (<= 14; stored as pairs)
 #define R1_TREE_SKIP_MIN 9     // DEFAULT kernel: exhaustive sweep for scenes of [R1_TREE_SKIP_MIN, R1_TREE_SKIP_MAX) hittable
 #define R1_TREE_SKIP_MAX 128   // spheres, box tree otherwise
 
@@ -51,10 +51,11 @@ struct R1DeviceScene
     uint32_t n_active;     // real entries
     uint32_t n_sweep;      // GROUPS, padded to a multiple of 8 (+8 prefetch); big scenes: of R1_TILE_SPHERES (+ one tile)
     // R1_VARIANT_BVH (r1_bvh.cpp): binary tree of boxes over the active spheres.  Node = 4 float4:
-    // {m0.xyz, w2} {e0.xyz, k} {m1.xyz, child0} {e1.xyz, child1}; child i has centre m_i and half
-    // extent e_i, inflated per ray by pad = w2 |m_i - o|^2 + k.  Child reference: bit 31 clear =
-    // inner node index; set = leaf, bits 28..30 sphere count, bits 0..27 first slot of
-    // bvh_prims {cx, cy, cz, radius_sq} / bvh_ids (active index).  Node 0 is the root.
+    // {m0x m1x m0y m1y} {m0z m1z e0x e1x} {e0y e1y e0z e1z} {w2 k child0 child1}; child i has
+    // centre m_i and half extent e_i, inflated per ray by pad = w2 |m_i - o|^2 + k.  Child
+    // reference: bit 31 clear = inner node index; set = leaf, bits 28..30 number of sphere PAIRS,
+    // bits 0..27 first pair of bvh_prims (2 float4 per pair {cx_a cx_b cy_a cy_b} {cz_a cz_b rsq_a
+    // rsq_b}) / bvh_ids (2 active indices per pair).  Node 0 is the root.
     const float4 *bvh_nodes;
     const float4 *bvh_prims;
     const uint32_t *bvh_ids;

@@ -21,6 +21,12 @@ def scene_arrays(sc):
     return a
 
 
+M = ((0, 2, 4), (1, 3, 5))    # node row: {m0x m1x m0y m1y} {m0z m1z e0x e1x} {e0y e1y e0z e1z} {w2 k child0 child1}
+E = ((6, 8, 10), (7, 9, 11))
+REF = (14, 15)
+EMPTY = 0xFFFFFFFF
+
+
 def walk(nodes):
     """Yields (node, child_slot, ref, m, e, w2, k) for every child reference in the tree."""
     stack = [0]
@@ -31,24 +37,25 @@ def walk(nodes):
         seen.add(n)
         row = nodes[n]
         refs = row.view(np.uint32)
-        for c, (mo, eo, ro) in enumerate(((0, 4, 11), (8, 12, 15))):
-            ref = int(refs[ro])
-            yield n, c, ref, row[mo:mo + 3].astype(np.float64), row[eo:eo + 3].astype(np.float64), float(row[3]), float(row[7])
+        for c in (0, 1):
+            ref = int(refs[REF[c]])
+            yield n, c, ref, row[list(M[c])].astype(np.float64), row[list(E[c])].astype(np.float64), float(row[12]), float(row[13])
             if not ref & LEAF:
                 stack.append(ref)
     assert len(seen) == len(nodes)
 
 
 def leaf_slots(ref):
-    first, cnt = ref & 0x0FFFFFFF, (ref >> 28) & 7
-    return range(first, first + cnt)
+    """id slots of a leaf reference: two per sphere pair (one may be EMPTY)."""
+    first, pairs = ref & 0x0FFFFFFF, (ref >> 28) & 7
+    return range(2 * first, 2 * (first + pairs))
 
 
 def subtree_slots(nodes, ref):
     if ref & LEAF:
         return list(leaf_slots(ref))
     row = nodes[ref].view(np.uint32)
-    return subtree_slots(nodes, int(row[11])) + subtree_slots(nodes, int(row[15]))
+    return subtree_slots(nodes, int(row[REF[0]])) + subtree_slots(nodes, int(row[REF[1]]))
 
 
 @pytest.mark.parametrize("kind,gw,gh", [("small", 0, 0), ("medium", 0, 0), ("large", 0, 0), ("grid", 64, 40), ("grid", 400, 250)])
@@ -59,7 +66,9 @@ def test_tree_structure(kind, gw, gh):
     info, nodes, ids = binding.bvh_describe(sc.spheres.contents)
     active = np.nonzero(a["inv_radius"] != 0)[0]
     assert info["spheres"] == len(active)
-    assert sorted(ids.tolist()) == active.tolist()          # each hittable sphere exactly once, placeholders never
+    real = ids[ids != EMPTY]
+    assert sorted(real.tolist()) == active.tolist()         # each hittable sphere exactly once, placeholders never
+    assert len(ids) == 2 * info["pairs"]
     assert 1 <= info["depth"] <= info["stack_entries"]
     c = np.stack([a["center_x"], a["center_y"], a["center_z"]], 1).astype(np.float64)
     r = np.sqrt(a["radius_sq"].astype(np.float64))
@@ -67,10 +76,10 @@ def test_tree_structure(kind, gw, gh):
     for n, ci, ref, m, e, w2, k in walk(nodes):
         if ref & LEAF:
             n_leaf += ((ref >> 28) & 7) > 0
-            slots = list(leaf_slots(ref))
+            slots = [q for q in leaf_slots(ref) if ids[q] != EMPTY]
             assert len(slots) <= 4
         elif len(nodes) <= 2000:
-            slots = subtree_slots(nodes, ref)
+            slots = [q for q in subtree_slots(nodes, ref) if ids[q] != EMPTY]
         else:
             continue  # big trees: leaves only (the inner boxes are unions of their children's by construction)
         for s in slots:
@@ -110,17 +119,17 @@ def traverse(nodes, o, d):
             n = stack.pop()
             row = nodes[n]
             refs = row.view(np.uint32)
-            w2, k = row[3], row[7]
-            for mo, eo, ro in ((0, 4, 11), (8, 12, 15)):
-                com = (row[mo:mo + 3] - o).astype(F)
+            w2, k = row[12], row[13]
+            for c in (0, 1):
+                com = (row[list(M[c])] - o).astype(F)
                 d2 = F(com[2] * com[2] + F(com[1] * com[1] + F(com[0] * com[0])))
                 pad = F(w2 * d2 + k)
                 a = (com * inv).astype(F)
-                b = ((row[eo:eo + 3] + pad).astype(F) * np.abs(inv)).astype(F)
+                b = ((row[list(E[c])] + pad).astype(F) * np.abs(inv)).astype(F)
                 tn = np.fmax(np.fmax(a[0] - b[0], a[1] - b[1]), a[2] - b[2])
                 tf = np.fmin(np.fmin(a[0] + b[0], a[1] + b[1]), a[2] + b[2])
                 if tn <= tf and tf >= 0:
-                    ref = int(refs[ro])
+                    ref = int(refs[REF[c]])
                     if ref & LEAF:
                         out.extend(leaf_slots(ref))
                     else:
@@ -156,7 +165,7 @@ def test_traversal_rule_presents_every_sphere_the_reference_flags(kind):
         if q % 7 == 0:
             d = np.array([0, 0, -1], F) if q % 2 else np.array([1, 0, 0], F)  # axis-parallel: infinite reciprocals
         flagged = set(np.nonzero(ref_flagged(cx, cy, cz, rsq, o, d) & active)[0].tolist())
-        shown = set(ids[traverse(nodes, o, d)].tolist())
+        shown = set(ids[traverse(nodes, o, d)].tolist()) - {EMPTY}
         assert flagged <= shown, (q, sorted(flagged - shown)[:5])
         shown_total += len(shown)
         flagged_total += len(flagged)
