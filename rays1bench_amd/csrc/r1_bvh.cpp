@@ -356,7 +356,8 @@ extern "C" int r1_bvh_describe(const r1_scene *s, int32_t leaf_max, r1_bvh_info 
     if (na == 0)
         x.push_back(0), y.push_back(0), z.push_back(0), r.push_back(0);
     R1Bvh b;
-    r1_build_bvh(na, x.data(), y.data(), z.data(), r.data(), leaf_max > 0 ? leaf_max : R1_BVH_LEAF, b);
+    r1_build_bvh(na, x.data(), y.data(), z.data(), r.data(),
+                 leaf_max > 0 ? leaf_max : (na > R1_MAX_ACTIVE_10BIT ? 2 * R1_BVH_LEAF : R1_BVH_LEAF), b);
     info->nodes = (int32_t)(b.nodes.size() / 16);
     info->leaves = (int32_t)b.n_leaves;
     info->depth = b.max_depth;

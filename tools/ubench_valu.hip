@@ -40,6 +40,54 @@ __global__ void __launch_bounds__(256) k(float *out, int iters, float sa, float 
                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
                               : "s"(sa), "v"(a0));)
         }
+        else if (MODE >= 4)
+        {
+            // one-operand-pattern probes of the instructions the tree kernel's node test is made of
+#define R1_PROBE(INS, T, C)                                                                                                              \
+    REP8(asm volatile(INS " %0, %0, %8\n " INS " %1, %1, %8\n " INS " %2, %2, %8\n " INS " %3, %3, %8\n " INS " %4, %4, %8\n " INS           \
+                          " %5, %5, %8\n " INS " %6, %6, %8\n " INS " %7, %7, %8"                                                          \
+                      : "+v"(T##0), "+v"(T##1), "+v"(T##2), "+v"(T##3), "+v"(T##4), "+v"(T##5), "+v"(T##6), "+v"(T##7)                    \
+                      : "v"(C));)
+            if (MODE == 4)
+            {
+                R1_PROBE("v_pk_add_f32", p, m2)
+            }
+            else if (MODE == 5)
+            {
+                R1_PROBE("v_pk_mul_f32", p, m2)
+            }
+            else if (MODE == 6)
+            {
+                R1_PROBE("v_add_f32", a, m)
+            }
+            else if (MODE == 7)
+            {
+                REP8(asm volatile("v_cvt_f32_f16 %0, %8\n v_cvt_f32_f16 %1, %8\n v_cvt_f32_f16 %2, %8\n v_cvt_f32_f16 %3, %8\n"
+                                  "v_cvt_f32_f16 %4, %8\n v_cvt_f32_f16 %5, %8\n v_cvt_f32_f16 %6, %8\n v_cvt_f32_f16 %7, %8"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                                  : "v"(m));)
+            }
+            else if (MODE == 8)
+            {
+                REP8(asm volatile("v_max3_f32 %0, %0, %8, %9\n v_max3_f32 %1, %1, %8, %9\n v_max3_f32 %2, %2, %8, %9\n v_max3_f32 %3, %3, %8, %9\n"
+                                  "v_max3_f32 %4, %4, %8, %9\n v_max3_f32 %5, %5, %8, %9\n v_max3_f32 %6, %6, %8, %9\n v_max3_f32 %7, %7, %8, %9"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                                  : "v"(m), "v"(sa));)
+            }
+            else
+            {
+                REP8(asm volatile("v_cvt_f32_f16_sdwa %0, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+                                  "v_cvt_f32_f16_sdwa %1, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+                                  "v_cvt_f32_f16_sdwa %2, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+                                  "v_cvt_f32_f16_sdwa %3, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+                                  "v_cvt_f32_f16_sdwa %4, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+                                  "v_cvt_f32_f16_sdwa %5, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+                                  "v_cvt_f32_f16_sdwa %6, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+                                  "v_cvt_f32_f16_sdwa %7, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                                  : "v"(m));)
+            }
+        }
         else
         {
             REP8(asm volatile("v_pk_fma_f32 %0, %8, %0, %9\n v_pk_fma_f32 %1, %8, %1, %9\n v_pk_fma_f32 %2, %8, %2, %9\n v_pk_fma_f32 %3, %8, %3, %9\n"
@@ -57,7 +105,7 @@ template <int MODE>
 static void run(const char *name, int cus, float *d)
 {
     const int iters = 4000;
-    for (int wps = 1; wps <= 8; wps *= 2)
+    for (int wps = (MODE >= 4 ? 4 : 1); wps <= 8; wps *= 2)
     {
         hipEvent_t e0, e1;
         hipEventCreate(&e0), hipEventCreate(&e1);
@@ -88,5 +136,11 @@ int main()
     run<1>("v_pk_fma_f32 (vgpr)", prop.multiProcessorCount, d);
     run<2>("v_fma_f32 (sgpr src0)", prop.multiProcessorCount, d);
     run<3>("v_pk_fma_f32 (sgpr-pair src0)", prop.multiProcessorCount, d);
+    run<4>("v_pk_add_f32", prop.multiProcessorCount, d);
+    run<5>("v_pk_mul_f32", prop.multiProcessorCount, d);
+    run<6>("v_add_f32", prop.multiProcessorCount, d);
+    run<7>("v_cvt_f32_f16", prop.multiProcessorCount, d);
+    run<8>("v_max3_f32", prop.multiProcessorCount, d);
+    run<9>("v_cvt_f32_f16_sdwa (high half)", prop.multiProcessorCount, d);
     return 0;
 }
