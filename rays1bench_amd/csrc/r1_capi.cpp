@@ -645,8 +645,17 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     // >= R1_SAMPLES_PER_LANE samples and let the other frames fill the CUs a small frame leaves.
     long long blocks = (long long)c->cus * per_cu;
     static const long long spl_env = getenv("R1_SAMPLES_PER_LANE") ? atoll(getenv("R1_SAMPLES_PER_LANE")) : R1_SAMPLES_PER_LANE;
-    const long long spl = throughput_mode ? (spl_env > 0 ? spl_env : 1) : 1;
-    const long long needed = ((long long)c->total_samples + R1_BLOCK * spl - 1) / (R1_BLOCK * spl);
+    static const long long minb_env = getenv("R1_MIN_BLOCKS") ? atoll(getenv("R1_MIN_BLOCKS")) : R1_MIN_BLOCKS;
+    long long needed = ((long long)c->total_samples + R1_BLOCK - 1) / R1_BLOCK;
+    if (throughput_mode)
+    {
+        // few, long-lived workgroups per frame (>= R1_SAMPLES_PER_LANE samples per lane), but not fewer
+        // than R1_MIN_BLOCKS while that still leaves R1_SAMPLES_PER_LANE_MIN samples per lane
+        const long long spl = spl_env > 0 ? spl_env : 1;
+        const long long hi = ((long long)c->total_samples + R1_BLOCK * spl - 1) / (R1_BLOCK * spl);
+        const long long lo = ((long long)c->total_samples + R1_BLOCK * R1_SAMPLES_PER_LANE_MIN - 1) / (R1_BLOCK * R1_SAMPLES_PER_LANE_MIN);
+        needed = std::max(hi, std::min(minb_env, lo));
+    }
     if (blocks > needed)
         blocks = needed;
     if (blocks < 1)
