@@ -623,8 +623,10 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     a.num_rays = (unsigned long long *)d_rays;
     a.stats = (variant == 3 || variant == 5) ? (unsigned long long *)((char *)c->counters.p + 128) : nullptr;
 
-    static const int gstack_env = getenv("R1_BVH_GSTACK") ? atoi(getenv("R1_BVH_GSTACK")) : 0;
-    const int big = (c->n_active > R1_MAX_ACTIVE_10BIT || ((variant == 4 || variant == 5) && gstack_env)) ? 1 : 0;
+    // BIG kernels: 32-bit hit indices and the attenuation stack in a global workspace (the packed
+    // LDS stack holds 10-bit indices).  Tried for the tree kernel on small scenes too (more
+    // workgroups per CU): 15 % slower.
+    const int big = c->n_active > R1_MAX_ACTIVE_10BIT ? 1 : 0;
     a.bvh_depth = c->bvh_depth > 0 ? c->bvh_depth : 1;
     if (c->occupancy[variant + 6 * big] == 0)
         R1_HIP(r1_trace_occupancy(variant, big, (variant == 4 || variant == 5) ? (size_t)a.bvh_depth * R1_BLOCK * 4 : 0,

@@ -5,7 +5,7 @@
 //   render_tile's pixel x sample loop      rayweek1.cpp:722-782   -> r1_trace_kernel + r1_resolve_kernel
 //   Camera::getRay / random_in_unit_disk   rayweek1.cpp:381-386 / :353-362
 //   color() bounce recursion               rayweek1.cpp:515-536   -> flattened register loop
-//   Hitable::hit (AVX2 sweep + resolve)    rayweek1.cpp:152-339   -> sweep_prefilter / sweep_reference
+//   Hitable::hit (AVX2 sweep + resolve)    rayweek1.cpp:152-339   -> sweep_prefilter / sweep_reference / sweep_bvh
 //   Lambertian/Metal/Dielectric::scatter   rayweek1.cpp:403-409 / :427-433 / :470-511
 //   TileRenderScheduler (atomic tile pop)  rayweek1.cpp:785-842   -> persistent waves + global sample queue
 //
@@ -13,7 +13,11 @@
 //   * one LANE per live path; a wave keeps its 64 lanes busy by refilling finished lanes from a
 //     global sample queue (guided chunks of R1_CHUNK_MIN..R1_CHUNK samples per atomic), so the
 //     bounce-count divergence of color() (1..51 rays per sample) costs no lanes;
-//   * the sphere table is wave-uniform: it is read with SCALAR loads (two alternating sets of
+//   * three interchangeable hit tests, bit-identical results (include/rays1.h R1_VARIANT_*): the
+//     reference's form over every sphere (sweep_reference), the grouped exhaustive sweep
+//     (sweep_prefilter, next two points) and a per-lane walk of a conservative box tree in front
+//     of the reference's per-sphere test (sweep_bvh; the reference has no such structure);
+//   * exhaustive sweep: the sphere table is wave-uniform: it is read with SCALAR loads (two alternating sets of
 //     s_load_dwordx16) and fed to the VALU as SGPR-pair operands of v_pk_fma_f32 — two spheres
 //     per instruction, no LDS round trip, no VGPRs.  (Scenes above 1023 spheres stream the table
 //     through LDS tiles instead: the scalar cache cannot sustain a 3 MB stream.);
