@@ -245,9 +245,10 @@ def main():
 
     if rank == 0:
         n_pad = info["spheres_padded"]
-        is_tree = info["kernel"] in (4, 5)
+        is_tree = info["kernel"] in (4, 5, 6)
         kernel_name = {1: "reference-form exhaustive sweep", 2: "grouped exhaustive sweep" + (" (LDS-tiled)" if info["spheres_active"] > 1023 else ""),
-                       3: "grouped exhaustive sweep + counters", 4: "box tree (R1_VARIANT_BVH)", 5: "box tree + counters"}[info["kernel"]]
+                       3: "grouped exhaustive sweep + counters", 4: "box tree (R1_VARIANT_BVH)", 5: "box tree + counters",
+                       6: "wavefront: generate / intersect / shade kernels, box tree (comparison build)"}[info["kernel"]]
         kernel_s = trace_ms_sum / max(frames, 1) * 1e-3
         alg_bytes = local_rays * 16.0 * n_pad  # 16 B per ray-sphere test x N_pad spheres per ray
         achieved = alg_bytes / kernel_s / 1e9
@@ -274,7 +275,9 @@ def main():
                        "kernel": kernel_name,
                        **({"bvh": {"nodes": info["bvh_nodes"], "leaves": info["bvh_leaves"], "depth": info["bvh_depth"]}} if is_tree else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "r1_trace_kernel", "kernel_ms": kernel_s * 1e3,
+                         "traffic": traffic if info["kernel"] != 6 else None,
+                         "kernel": "r1_trace_kernel" if info["kernel"] != 6 else "r1_wf_generate + 51 x (r1_wf_intersect, r1_wf_shade)",
+                         "kernel_ms": kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          # with several frames in flight the launches overlap (launch_overlap = sum of launch
                          # durations / elapsed): `achieved` is per launch as the contract defines it,

@@ -112,8 +112,11 @@ enum
     R1_VARIANT_BVH = 4,       /* optional spatial index (the reference has none, README.md:163): a conservative
                                  box tree chooses the spheres given to the reference's per-sphere test; results
                                  are bit-identical to the exhaustive sweeps   */
-    R1_VARIANT_BVH_STATS = 5  /* BVH plus traversal counters (diagnostic; r1_last_stats slots [2] node-loop trips,
+    R1_VARIANT_BVH_STATS = 5, /* BVH plus traversal counters (diagnostic; r1_last_stats slots [2] node-loop trips,
                                  [3] leaf-loop trips, [5] sphere tests, [9] node visits)                          */
+    R1_VARIANT_WAVEFRONT = 6  /* the same tracer as separate generate / intersect / shade kernels with the paths
+                                 and per-level queues in HBM; a comparison build: same pixels,
+                                 slower than the megakernel; frames of <= 2^24 sample slots       */
 };
 
 typedef struct r1_context r1_context; /* opaque: device, stream, events, workspace */

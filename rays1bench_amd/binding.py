@@ -15,7 +15,7 @@ LIBDIR = os.path.join(HERE, "lib")
 
 R1_OK, R1_EINVAL, R1_ENODEVICE, R1_EHIP, R1_ENOMEM, R1_ELIMIT = 0, -1, -2, -3, -4, -5
 SCENE_SMALL, SCENE_MEDIUM, SCENE_LARGE, SCENE_GRID = 0, 1, 2, 3
-VARIANT_DEFAULT, VARIANT_REFERENCE, VARIANT_PREFILTER, VARIANT_STATS, VARIANT_BVH, VARIANT_BVH_STATS = 0, 1, 2, 3, 4, 5
+VARIANT_DEFAULT, VARIANT_REFERENCE, VARIANT_PREFILTER, VARIANT_STATS, VARIANT_BVH, VARIANT_BVH_STATS, VARIANT_WAVEFRONT = 0, 1, 2, 3, 4, 5, 6
 
 
 class R1Error(RuntimeError):

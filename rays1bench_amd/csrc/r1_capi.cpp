@@ -22,6 +22,7 @@
 
 extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int big, int blocks, hipStream_t stream);
 extern "C" hipError_t r1_launch_resolve(const R1ResolveArgs *args, hipStream_t stream);
+extern "C" hipError_t r1_launch_wavefront(R1WaveArgs *w, int blocks, hipStream_t stream);
 extern "C" hipError_t r1_launch_assemble(const void *blocks, void *rgb, int width, int height, int tile_w, int tile_h, int tiles_x,
                                          int tiles_total, int num_shards, int tiles_per_shard, size_t shard_stride, hipStream_t stream);
 extern "C" hipError_t r1_trace_occupancy(int variant, int big, size_t dyn_lds, int *blocks_per_cu);
@@ -87,6 +88,7 @@ struct r1_context
     // scene
     DevBuf sweep, exact, shade, mat, members;
     DevBuf bvh_nodes, bvh_prims, bvh_ids; // R1_VARIANT_BVH (r1_bvh.cpp)
+    DevBuf wf_paths, wf_hits, wf_queue, wf_counts; // R1_VARIANT_WAVEFRONT workspace
     uint32_t n_bvh_nodes = 0, n_bvh_leaves = 0;
     int bvh_depth = 0;
     uint32_t n_active = 0, n_sweep = 0, n_padded_scene = 0, n_groups = 0, n_multi = 0;
@@ -100,7 +102,7 @@ struct r1_context
     bool tile_key_valid = false;
     uint32_t n_local_tiles = 0, total_samples = 0, full = 0;
 
-    int occupancy[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // [variant + 6*big]
+    int occupancy[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // [variant + 8*big]
     DevBuf gstack; // blocks per CU of the trace kernel, by variant
 
     r1_launch_info info;
@@ -197,6 +199,7 @@ extern "C" void r1_destroy(r1_context *c)
         (void)hipStreamSynchronize(c->stream);
     release(c->sweep), release(c->exact), release(c->shade), release(c->mat), release(c->members);
     release(c->bvh_nodes), release(c->bvh_prims), release(c->bvh_ids);
+    release(c->wf_paths), release(c->wf_hits), release(c->wf_queue), release(c->wf_counts);
     release(c->gstack), release(c->counters), release(c->samples), release(c->image);
     for (hipEvent_t e : c->ring)
         (void)hipEventDestroy(e);
@@ -579,6 +582,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     case R1_VARIANT_STATS: variant = 3; break;
     case R1_VARIANT_BVH: variant = 4; break;
     case R1_VARIANT_BVH_STATS: variant = 5; break;
+    case R1_VARIANT_WAVEFRONT: variant = 6; break;
     case R1_VARIANT_DEFAULT: variant = tree_default ? 4 : 2; break;
     default: variant = 2; break;
     }
@@ -628,10 +632,10 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     // workgroups per CU): 15 % slower.
     const int big = c->n_active > R1_MAX_ACTIVE_10BIT ? 1 : 0;
     a.bvh_depth = c->bvh_depth > 0 ? c->bvh_depth : 1;
-    if (c->occupancy[variant + 6 * big] == 0)
+    if (c->occupancy[variant + 8 * big] == 0)
         R1_HIP(r1_trace_occupancy(variant, big, (variant == 4 || variant == 5) ? (size_t)a.bvh_depth * R1_BLOCK * 4 : 0,
-                                  &c->occupancy[variant + 6 * big]));
-    int per_cu = c->occupancy[variant + 6 * big];
+                                  &c->occupancy[variant + 8 * big]));
+    int per_cu = c->occupancy[variant + 8 * big];
     if (per_cu < 1)
         per_cu = 1;
     if (per_cu > 8)
@@ -682,8 +686,37 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
         R1_HIP(hipMemsetAsync((char *)c->counters.p + 128, 0, 128, st));
     R1_HIP(hipMemsetAsync(d_rays, 0, 8, st));
     R1_HIP(hipEventRecord(e0, st));
-    if (c->total_samples)
+    if (c->total_samples && variant != 6)
         R1_HIP(r1_launch_trace(&a, variant, big, (int)blocks, st));
+    if (c->total_samples && variant == 6)
+    {
+        // wavefront variant: path state, per-level queues and the attenuation stack live in HBM
+        const size_t n = c->total_samples;
+        if (n > ((size_t)1 << 24))
+        {
+            r1_set_error("R1_VARIANT_WAVEFRONT keeps every path of the frame in memory: %zu sample slots > 2^24", n);
+            return R1_ELIMIT;
+        }
+        if ((rc = ensure(c->wf_paths, 3 * n * 16)) || (rc = ensure(c->wf_hits, n * 8)) || (rc = ensure(c->wf_queue, 2 * n * 4)) ||
+            (rc = ensure(c->wf_counts, (R1_STACK_ENTRIES + 2) * 4)) || (rc = ensure(c->gstack, (size_t)R1_STACK_ENTRIES * n * 4)))
+            return rc;
+        R1WaveArgs w;
+        memset(&w, 0, sizeof(w));
+        w.t = a;
+        w.t.gstack = (uint32_t *)c->gstack.p;
+        w.paths = (float4 *)c->wf_paths.p;
+        w.hits = (float2 *)c->wf_hits.p;
+        w.queue[0] = (uint32_t *)c->wf_queue.p;
+        w.queue[1] = (uint32_t *)c->wf_queue.p + n;
+        w.counts = (uint32_t *)c->wf_counts.p;
+        w.n_paths = (uint32_t)n;
+        long long wb = (long long)((n + R1_BLOCK - 1) / R1_BLOCK);
+        if (wb > (long long)c->cus * 8)
+            wb = (long long)c->cus * 8;
+        R1_HIP(hipMemsetAsync(c->wf_counts.p, 0, (R1_STACK_ENTRIES + 2) * 4, st));
+        R1_HIP(r1_launch_wavefront(&w, (int)wb, st));
+        blocks = wb;
+    }
     R1_HIP(hipEventRecord(e1, st));
 
     R1ResolveArgs r;
@@ -708,8 +741,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     c->info.spheres_padded = (int32_t)c->n_padded_scene;
     c->info.groups = (int32_t)c->n_groups;
     c->info.samples = c->total_samples;
-    c->info.kernel = variant == 1 ? R1_VARIANT_REFERENCE : variant == 3 ? R1_VARIANT_STATS : variant == 4 ? R1_VARIANT_BVH
-                     : variant == 5 ? R1_VARIANT_BVH_STATS : R1_VARIANT_PREFILTER;
+    c->info.kernel = variant; // internal numbering = the public enum (DEFAULT resolved)
     c->info.bvh_nodes = (int32_t)c->n_bvh_nodes;
     c->info.bvh_leaves = (int32_t)c->n_bvh_leaves;
     c->info.bvh_depth = c->bvh_depth;

@@ -94,6 +94,19 @@ struct R1TraceArgs
     int32_t bvh_depth;            // tree kernels: traversal stack entries per thread (dynamic LDS = depth * R1_BLOCK * 4)
 };
 
+// Wavefront variant (R1_VARIANT_WAVEFRONT): the same path tracer split into
+// generate / intersect / shade kernels with the paths and per-level queues in HBM.
+struct R1WaveArgs
+{
+    R1TraceArgs t;        // scene, camera, frame, samples, num_rays; gstack = attenuation stack [entry][path]
+    float4 *paths;        // [3][n_paths]: {ox oy oz dx} {dy dz s_scalar s0} {s1 s2 k rays|depth<<8|sp<<16}
+    float2 *hits;         // [n_paths] {t, bit_cast<float>(hit index)}
+    uint32_t *queue[2];   // path slots alive at the current / next level
+    uint32_t *counts;     // [R1_STACK_ENTRIES + 2] queue length per level (zeroed before the frame)
+    uint32_t n_paths;     // = total_samples: path slot = sample slot
+    int32_t level;        // color() depth this launch works on
+};
+
 struct R1ResolveArgs
 {
     const float4 *samples;

@@ -267,7 +267,7 @@ extern "C" int r1_params_check(const r1_params *p)
 {
     if (!p || p->width <= 0 || p->height <= 0 || p->spp <= 0 || p->tile_w <= 0 || p->tile_h <= 0 || p->num_shards < 1 ||
         p->shard < 0 || p->shard >= p->num_shards || p->max_bounces < 1 || p->max_bounces > R1_MAX_BOUNCES_LIMIT ||
-        p->variant < R1_VARIANT_DEFAULT || p->variant > R1_VARIANT_BVH_STATS)
+        p->variant < R1_VARIANT_DEFAULT || p->variant > R1_VARIANT_WAVEFRONT)
     {
         r1_set_error("bad r1_params (size %dx%dx%d, tile %dx%d, shard %d/%d, max_bounces %d, variant %d)", p ? p->width : 0,
                      p ? p->height : 0, p ? p->spp : 0, p ? p->tile_w : 0, p ? p->tile_h : 0, p ? p->shard : 0, p ? p->num_shards : 0,

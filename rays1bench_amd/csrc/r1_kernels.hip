@@ -762,6 +762,115 @@ __device__ __forceinline__ bool start_sample(const R1TraceArgs &A, Path &p, uint
     return true;
 }
 
+// ---- one color() level after the hit test (rayweek1.cpp:517-534): count the ray, then either
+// scatter (new ray in p, hit index pushed on the attenuation stack) or finish the path: sky
+// colour times the stacked attenuations, or black.  Returns true when the path has ended, with
+// its radiance in `col`.  Shared by the megakernel and the wavefront kernels.
+template <bool BIG>
+__device__ __forceinline__ bool shade_level(const R1TraceArgs &A, Path &p, const int hit, const float t_hit, uint32_t *s_stack,
+                                            const uint32_t gstride, const uint32_t gtid, const int tid, V3 &col)
+{
+    ++p.rays; // rayweek1.cpp:517
+    bool done = false;
+    col = mk(0, 0, 0);
+    if (hit >= 0)
+    {
+        if (p.depth < A.max_bounces)
+        {
+            // hit record (rayweek1.cpp:316-322)
+            const f4 e = ((const f4 *)A.scene.exact)[hit];
+            const f4 sh = ((const f4 *)A.scene.shade)[hit];
+            const f4 mt = ((const f4 *)A.scene.mat)[hit];
+            const V3 hp = vadd(p.o, vscale(p.d, t_hit));
+            const V3 n = vscale(vsub(hp, mk(e.x, e.y, e.z)), sh.x);
+            const uint32_t type = __float_as_uint(mt.x);
+            // Lambertian and Metal both draw random_in_unit_sphere from the x4 stream
+            // (rayweek1.cpp:405, :430; Metal even with fuzz == 0): one shared loop
+            V3 rius = mk(0, 0, 0);
+            if (type != 2u)
+                rius = random_in_unit_sphere(p);
+            V3 dir; // un-normalised scattered direction; Ray::Ray normalises (rayweek1.cpp:107)
+            if (type == 0u)
+            {
+                // Lambertian::scatter rayweek1.cpp:403-409
+                const V3 target = vadd(vadd(hp, n), rius);
+                dir = vsub(target, hp);
+            }
+            else if (type == 1u)
+            {
+                // Metal::scatter rayweek1.cpp:427-433; reflect :414-417
+                const V3 refl = vsub(p.d, vscale(n, 2.0f * vdot(p.d, n)));
+                dir = vadd(refl, vscale(rius, mt.y));
+            }
+            else
+            {
+                // Dielectric::scatter rayweek1.cpp:470-511 (attenuation 1: nothing to push)
+                const float ref_idx = mt.y;
+                const float ddn = vdot(p.d, n);
+                const V3 reflected = vsub(p.d, vscale(n, 2.0f * ddn));
+                V3 outward;
+                float ni_over_nt, cosine;
+                if (ddn > 0)
+                {
+                    outward = vneg(n);
+                    ni_over_nt = ref_idx;
+                    cosine = ref_idx * ddn;
+                }
+                else
+                {
+                    outward = n;
+                    ni_over_nt = mt.z; // 1.0f / _refIdx, divided on the host (same IEEE division)
+                    cosine = -ddn;
+                }
+                // refract rayweek1.cpp:439-452
+                const float dt = vdot(p.d, outward);
+                const float discriminant = 1.0f - ni_over_nt * ni_over_nt * (1.0f - dt * dt);
+                float reflect_prob = 1.0f;
+                V3 refracted = mk(0, 0, 0);
+                if (discriminant > 0)
+                {
+                    refracted = vsub(vscale(vsub(p.d, vscale(outward, dt)), ni_over_nt), vscale(outward, ieee_sqrt(discriminant)));
+                    // schlick rayweek1.cpp:454-459; r0 = ((1 - ref)/(1 + ref))^2 comes from the host
+                    const float r0 = mt.w;
+                    reflect_prob = r0 + (1.0f - r0) * pow5(1.0f - cosine);
+                }
+                dir = (rand01(p.s_scalar) < reflect_prob) ? reflected : refracted;
+            }
+            const V3 nd = vunit(dir);
+            p.o = hp;
+            p.d = nd;
+            if (type == 2u || type == 0u || vdot(nd, n) > 0)
+            {
+                if (type != 2u)
+                {
+                    stack_push<BIG>(s_stack, A.gstack, gstride, gtid, tid, p.sp, (uint32_t)hit);
+                    ++p.sp;
+                }
+            }
+            else
+                done = true; // Metal::scatter() == false -> Vec3(0,0,0), rayweek1.cpp:432, :528
+            ++p.depth;
+        }
+        else
+            done = true; // depth == MAX_BOUNCES: no scatter, no draws, black (rayweek1.cpp:523-528)
+    }
+    else
+    {
+        // miss: sky (rayweek1.cpp:532-534), lerp = (1 - t) * a + t * b (mymath.h:212-216)
+        const float t = 0.5f * (p.d.y + 1.0f);
+        const float omt = 1.0f - t;
+        col = mk(omt * 1.0f + t * 0.5f, omt * 1.0f + t * 0.7f, omt * 1.0f + t * 1.0f);
+        // unwind: attenuation * color(...) innermost first (rayweek1.cpp:525)
+        for (int e = p.sp - 1; e >= 0; --e)
+        {
+            const float4 sh = A.scene.shade[stack_get<BIG>(s_stack, A.gstack, gstride, gtid, tid, e)];
+            col = mk(sh.y * col.x, sh.z * col.y, sh.w * col.z);
+        }
+        done = true;
+    }
+    return done;
+}
+
 } // namespace
 
 // ============================================================================================
@@ -891,105 +1000,8 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
 
         if (alive)
         {
-            ++p.rays; // rayweek1.cpp:517
-            bool done = false;
-            V3 col = mk(0, 0, 0);
-            if (hit >= 0)
-            {
-                if (p.depth < A.max_bounces)
-                {
-                    // hit record (rayweek1.cpp:316-322)
-                    const f4 e = ((const f4 *)A.scene.exact)[hit];
-                    const f4 sh = ((const f4 *)A.scene.shade)[hit];
-                    const f4 mt = ((const f4 *)A.scene.mat)[hit];
-                    const V3 hp = vadd(p.o, vscale(p.d, t_hit));
-                    const V3 n = vscale(vsub(hp, mk(e.x, e.y, e.z)), sh.x);
-                    const uint32_t type = __float_as_uint(mt.x);
-                    // Lambertian and Metal both draw random_in_unit_sphere from the x4 stream
-                    // (rayweek1.cpp:405, :430; Metal even with fuzz == 0): one shared loop
-                    V3 rius = mk(0, 0, 0);
-                    if (type != 2u)
-                        rius = random_in_unit_sphere(p);
-                    V3 dir; // un-normalised scattered direction; Ray::Ray normalises (rayweek1.cpp:107)
-                    if (type == 0u)
-                    {
-                        // Lambertian::scatter rayweek1.cpp:403-409
-                        const V3 target = vadd(vadd(hp, n), rius);
-                        dir = vsub(target, hp);
-                    }
-                    else if (type == 1u)
-                    {
-                        // Metal::scatter rayweek1.cpp:427-433; reflect :414-417
-                        const V3 refl = vsub(p.d, vscale(n, 2.0f * vdot(p.d, n)));
-                        dir = vadd(refl, vscale(rius, mt.y));
-                    }
-                    else
-                    {
-                        // Dielectric::scatter rayweek1.cpp:470-511 (attenuation 1: nothing to push)
-                        const float ref_idx = mt.y;
-                        const float ddn = vdot(p.d, n);
-                        const V3 reflected = vsub(p.d, vscale(n, 2.0f * ddn));
-                        V3 outward;
-                        float ni_over_nt, cosine;
-                        if (ddn > 0)
-                        {
-                            outward = vneg(n);
-                            ni_over_nt = ref_idx;
-                            cosine = ref_idx * ddn;
-                        }
-                        else
-                        {
-                            outward = n;
-                            ni_over_nt = mt.z; // 1.0f / _refIdx, divided on the host (same IEEE division)
-                            cosine = -ddn;
-                        }
-                        // refract rayweek1.cpp:439-452
-                        const float dt = vdot(p.d, outward);
-                        const float discriminant = 1.0f - ni_over_nt * ni_over_nt * (1.0f - dt * dt);
-                        float reflect_prob = 1.0f;
-                        V3 refracted = mk(0, 0, 0);
-                        if (discriminant > 0)
-                        {
-                            refracted = vsub(vscale(vsub(p.d, vscale(outward, dt)), ni_over_nt), vscale(outward, ieee_sqrt(discriminant)));
-                            // schlick rayweek1.cpp:454-459; r0 = ((1 - ref)/(1 + ref))^2 comes from the host
-                            const float r0 = mt.w;
-                            reflect_prob = r0 + (1.0f - r0) * pow5(1.0f - cosine);
-                        }
-                        dir = (rand01(p.s_scalar) < reflect_prob) ? reflected : refracted;
-                    }
-                    const V3 nd = vunit(dir);
-                    p.o = hp;
-                    p.d = nd;
-                    if (type == 2u || type == 0u || vdot(nd, n) > 0)
-                    {
-                        if (type != 2u)
-                        {
-                            stack_push<BIG>(s_stack, A.gstack, gstride, gtid, tid, p.sp, (uint32_t)hit);
-                            ++p.sp;
-                        }
-                    }
-                    else
-                        done = true; // Metal::scatter() == false -> Vec3(0,0,0), rayweek1.cpp:432, :528
-                    ++p.depth;
-                }
-                else
-                    done = true; // depth == MAX_BOUNCES: no scatter, no draws, black (rayweek1.cpp:523-528)
-            }
-            else
-            {
-                // miss: sky (rayweek1.cpp:532-534), lerp = (1 - t) * a + t * b (mymath.h:212-216)
-                const float t = 0.5f * (p.d.y + 1.0f);
-                const float omt = 1.0f - t;
-                col = mk(omt * 1.0f + t * 0.5f, omt * 1.0f + t * 0.7f, omt * 1.0f + t * 1.0f);
-                // unwind: attenuation * color(...) innermost first (rayweek1.cpp:525)
-                for (int e = p.sp - 1; e >= 0; --e)
-                {
-                    const float4 sh = A.scene.shade[stack_get<BIG>(s_stack, A.gstack, gstride, gtid, tid, e)];
-                    col = mk(sh.y * col.x, sh.z * col.y, sh.w * col.z);
-                }
-                done = true;
-            }
-            if (done)
+            V3 col;
+            if (shade_level<BIG>(A, p, hit, t_hit, s_stack, gstride, gtid, tid, col))
             {
                 A.samples[p.k] = make_float4(col.x, col.y, col.z, __uint_as_float(p.rays));
                 lane_rays += p.rays;
@@ -1039,6 +1051,131 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
         atomicAdd(A.num_rays, lane_rays);
 }
 
+
+// ============================================================================================
+// Wavefront variant (R1_VARIANT_WAVEFRONT; SURVEY.md §8f-3 "the step either side of the
+// megakernel"): generate -> [intersect -> shade] x (max_bounces + 1) with the path state and
+// one queue of live path slots per color() level in HBM.  Same device functions as the
+// megakernel (start_sample, sweep_bvh, shade_level), so the samples are bit-identical; what
+// differs is where the state lives between steps.  Measured against the megakernel in
+// DESIGN.md §4.5.
+// ============================================================================================
+namespace
+{
+
+// all lanes of the wave call this together; lanes with `want` get consecutive queue slots
+__device__ __forceinline__ void wave_append(uint32_t *counter, uint32_t *queue, const bool want, const uint32_t value)
+{
+    const unsigned long long m = __ballot(want);
+    if (m == 0ull)
+        return;
+    const int lane = (int)(threadIdx.x & 63u);
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader)
+        base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    if (want)
+        queue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
+}
+
+__device__ __forceinline__ void path_store(const R1WaveArgs &W, const uint32_t slot, const Path &p)
+{
+    W.paths[slot] = make_float4(p.o.x, p.o.y, p.o.z, p.d.x);
+    W.paths[(size_t)W.n_paths + slot] = make_float4(p.d.y, p.d.z, __uint_as_float(p.s_scalar), __uint_as_float(p.s0));
+    W.paths[2 * (size_t)W.n_paths + slot] = make_float4(__uint_as_float(p.s1), __uint_as_float(p.s2), __uint_as_float(p.k),
+                                                        __uint_as_float(p.rays | ((uint32_t)p.depth << 8) | ((uint32_t)p.sp << 16)));
+}
+
+__device__ __forceinline__ void path_load(const R1WaveArgs &W, const uint32_t slot, Path &p)
+{
+    const float4 a = W.paths[slot], b = W.paths[(size_t)W.n_paths + slot], c = W.paths[2 * (size_t)W.n_paths + slot];
+    p.o = mk(a.x, a.y, a.z);
+    p.d = mk(a.w, b.x, b.y);
+    p.s_scalar = __float_as_uint(b.z), p.s0 = __float_as_uint(b.w);
+    p.s1 = __float_as_uint(c.x), p.s2 = __float_as_uint(c.y);
+    p.k = __float_as_uint(c.z);
+    const uint32_t packed = __float_as_uint(c.w);
+    p.rays = packed & 255u, p.depth = (int)((packed >> 8) & 255u), p.sp = (int)((packed >> 16) & 255u);
+}
+
+} // namespace
+
+// sample slot k -> primary ray (rayweek1.cpp:759-760) in path slot k; void slots are skipped
+__global__ void __launch_bounds__(R1_BLOCK) r1_wf_generate(const R1WaveArgs W)
+{
+    const uint32_t stride = gridDim.x * R1_BLOCK;
+    const uint32_t rounds = (W.n_paths + stride - 1) / stride; // every lane makes the same number of trips (wave_append)
+    for (uint32_t r = 0; r < rounds; ++r)
+    {
+        const uint32_t k = r * stride + blockIdx.x * R1_BLOCK + threadIdx.x;
+        Path p;
+        bool valid = false;
+        if (k < W.n_paths)
+            valid = start_sample(W.t, p, k);
+        if (valid)
+            path_store(W, k, p);
+        wave_append(&W.counts[0], W.queue[0], valid, k);
+    }
+}
+
+// Hitable::hit for every path of the level's queue (rayweek1.cpp:519)
+__global__ void __launch_bounds__(R1_BLOCK) r1_wf_intersect(const R1WaveArgs W)
+{
+    extern __shared__ uint32_t s_trav[];
+    const uint32_t n = W.counts[W.level];
+    const uint32_t *q = W.queue[W.level & 1];
+    const uint32_t stride = gridDim.x * R1_BLOCK;
+    for (uint32_t i = blockIdx.x * R1_BLOCK + threadIdx.x; i < n; i += stride)
+    {
+        const uint32_t slot = q[i];
+        const float4 a = W.paths[slot], b = W.paths[(size_t)W.n_paths + slot];
+        float t_hit = FLT_MAX;
+        int hit = -1;
+        sweep_bvh<false>(W.t.scene, true, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), t_hit, hit, s_trav, (int)threadIdx.x, nullptr);
+        W.hits[slot] = make_float2(t_hit, __int_as_float(hit));
+    }
+}
+
+// the rest of color() for the level: scatter into the next level's queue, or finish the sample
+__global__ void __launch_bounds__(R1_BLOCK) r1_wf_shade(const R1WaveArgs W)
+{
+    const uint32_t n = W.counts[W.level];
+    const uint32_t *q = W.queue[W.level & 1];
+    uint32_t *qn = W.queue[(W.level + 1) & 1];
+    const uint32_t stride = gridDim.x * R1_BLOCK;
+    const uint32_t rounds = (n + stride - 1) / stride;
+    unsigned long long lane_rays = 0;
+    for (uint32_t r = 0; r < rounds; ++r)
+    {
+        const uint32_t i = r * stride + blockIdx.x * R1_BLOCK + threadIdx.x;
+        bool goes_on = false;
+        uint32_t slot = 0;
+        if (i < n)
+        {
+            slot = q[i];
+            Path p;
+            path_load(W, slot, p);
+            const float2 h = W.hits[slot];
+            V3 col;
+            if (shade_level<true>(W.t, p, __float_as_int(h.y), h.x, nullptr, W.n_paths, slot, (int)threadIdx.x, col))
+            {
+                W.t.samples[p.k] = make_float4(col.x, col.y, col.z, __uint_as_float(p.rays));
+                lane_rays += p.rays;
+            }
+            else
+            {
+                path_store(W, slot, p);
+                goes_on = true;
+            }
+        }
+        wave_append(&W.counts[W.level + 1], qn, goes_on, slot);
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        lane_rays += __shfl_down(lane_rays, off, 64);
+    if ((threadIdx.x & 63u) == 0 && lane_rays)
+        atomicAdd(W.t.num_rays, lane_rays);
+}
 
 // ============================================================================================
 // Resolve: one thread per pixel of this shard; sums the spp samples in sample order and
@@ -1131,6 +1268,20 @@ extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int 
         hipLaunchKernelGGL((r1_trace_kernel<2, false, true>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
     else
         hipLaunchKernelGGL((r1_trace_kernel<2, false, false>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
+    return hipGetLastError();
+}
+
+// generate + (max_bounces + 1) x (intersect, shade); every launch reads its queue length on the device
+extern "C" hipError_t r1_launch_wavefront(R1WaveArgs *w, int blocks, hipStream_t stream)
+{
+    const size_t trav = (size_t)w->t.bvh_depth * R1_BLOCK * sizeof(uint32_t);
+    hipLaunchKernelGGL(r1_wf_generate, dim3(blocks), dim3(R1_BLOCK), 0, stream, *w);
+    for (int level = 0; level <= w->t.max_bounces; ++level)
+    {
+        w->level = level;
+        hipLaunchKernelGGL(r1_wf_intersect, dim3(blocks), dim3(R1_BLOCK), trav, stream, *w);
+        hipLaunchKernelGGL(r1_wf_shade, dim3(blocks), dim3(R1_BLOCK), 0, stream, *w);
+    }
     return hipGetLastError();
 }
 

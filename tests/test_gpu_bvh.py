@@ -241,3 +241,38 @@ def test_bvh_shards_and_tiles(renderer):
     for shard in range(3):
         total += renderer.render(r1.make_params(w, h, spp, 77, shard=shard, num_shards=3, variant=BVH))[1]
     assert total == base[1]
+
+
+# ---- wavefront variant: same device functions, state in HBM between the steps ----
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("small", 160, 120, 8), ("medium", 200, 120, 5), ("large", 256, 192, 6)])
+def test_wavefront_variant_equals_megakernel_and_oracle(renderer, name, w, h, spp):
+    sc = MAKE[name](w, h)
+    renderer.set_scene(sc)
+    a = renderer.render_samples(r1.make_params(w, h, spp, 4242, variant=binding.VARIANT_WAVEFRONT))
+    assert renderer.launch_info()["kernel"] == binding.VARIANT_WAVEFRONT
+    b = renderer.render_samples(r1.make_params(w, h, spp, 4242, variant=BVH))
+    assert same(a, b)
+    oimg, orays, osamples = r1o.render_frame(oracle_scene(sc), oparams(r1.make_params(w, h, spp, 4242)), want_samples=True)
+    differing = (a[2].view(np.uint32) != osamples.view(np.uint32)).any(1)
+    assert differing.mean() <= 1e-5 and abs(a[1] - orays) <= 51 * differing.sum()
+
+
+def test_wavefront_variant_edges(renderer):
+    """Ragged tiles (void slots), shards, bounce limits 1 and 51, a 1x1 frame, an empty scene."""
+    renderer.set_scene(r1.create_large_scene(75, 53))
+    for kw in (dict(), dict(max_bounces=1), dict(max_bounces=51), dict(tile_w=7, tile_h=5)):
+        a = renderer.render_samples(r1.make_params(75, 53, 3, 9, variant=binding.VARIANT_WAVEFRONT, **kw))
+        b = renderer.render_samples(r1.make_params(75, 53, 3, 9, variant=BVH, **kw))
+        assert same(a, b), kw
+    for shard in range(3):
+        a = renderer.render(r1.make_params(75, 53, 3, 9, shard=shard, num_shards=3, variant=binding.VARIANT_WAVEFRONT))
+        b = renderer.render(r1.make_params(75, 53, 3, 9, shard=shard, num_shards=3, variant=BVH))
+        assert a[0].tobytes() == b[0].tobytes() and a[1] == b[1]
+    renderer.set_scene(r1.create_large_scene(1, 1))
+    assert same(renderer.render_samples(r1.make_params(1, 1, 1, 1, variant=binding.VARIANT_WAVEFRONT)),
+                renderer.render_samples(r1.make_params(1, 1, 1, 1, variant=BVH)))
+    with pytest.raises(binding.R1Error):  # the whole frame's paths must fit the workspace limit (2^24 slots)
+        renderer.set_scene(r1.create_large_scene(4096, 4096))
+        renderer.render(r1.make_params(4096, 4096, 2, 1, variant=binding.VARIANT_WAVEFRONT))
