@@ -75,6 +75,33 @@ def cpu_baseline(scene, w, h, spp):
             "sample": f"{scene} {w}x{h}x{spp}: {n} frames through oracle/r1_oracle.c r1o_render_threads, {secs:.1f} s"}
 
 
+def cpu_table(w, h, spp):
+    """SURVEY.md §8f-4 within the rules (the CPU side lives in oracle/, reachable only from here):
+    the reference's README-style table on this box's host cores — step13 multi-threaded and
+    single-threaded (the reference's own TileRenderScheduler/render_tile, oracle/_ref) for the
+    three scenes, and step1 (oracle port) on the small scene.  Bounded to a few seconds per entry."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import r1o
+    rows = []
+    binary = r1o.ref_binary(True) or r1o.ref_binary(False)
+    for scene in ("small", "medium", "large"):
+        for threads, (fw, fh) in ((0, (w, h)), (1, (max(w // 2, 1), max(h // 2, 1)))):
+            if not binary:
+                break
+            try:
+                out = subprocess.run([binary, "bench", scene, str(fw), str(fh), str(spp), str(threads), "3"], capture_output=True, timeout=300)
+                rec = [json.loads(l) for l in out.stdout.decode().strip().splitlines()][1:]
+                rows.append({"version": "step13", "scene": scene, "threads": rec[0]["threads"], "frame": f"{fw}x{fh}x{spp}",
+                             "mrays_per_s": sum(r["rays"] for r in rec) / sum(r["seconds"] for r in rec) / 1e6, "kind": "reference"})
+            except Exception as e:
+                rows.append({"version": "step13", "scene": scene, "threads": threads, "error": str(e)})
+    t0 = time.perf_counter()
+    rays = r1o.step1_small(w // 2, h // 2, 1)[1]
+    rows.append({"version": "step1", "scene": "small", "threads": 1, "frame": f"{w // 2}x{h // 2}x1",
+                 "mrays_per_s": rays / (time.perf_counter() - t0) / 1e6, "kind": "port"})
+    return rows
+
+
 def cpu_baseline_grid(sc, w, h):
     """Scenes beyond the reference's MAX_SPHERES = 1024 (rayweek1.cpp:174) cannot go through its
     binaries: the oracle port's threaded exhaustive sweep, on a frame shrunk to ~10-30 s."""
@@ -116,6 +143,9 @@ def main():
     ap.add_argument("--check", action="store_true",
                     help="after the timed region compare the gathered + assembled image and ray count with an unsharded render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-table", action="store_true",
+                    help="also time the reference's step13 (all threads / 1 thread) on the three scenes and the step1 port "
+                         "on the host cores (cpu_baseline.table; adds ~30 s)")
     args = ap.parse_args()
 
     # Frames in flight only overlap when their streams sit on different hardware queues; the
@@ -319,6 +349,8 @@ def main():
                 except Exception as e:  # the baseline is reported, never required
                     out["cpu_baseline"] = {"value": None, "unit": "mrays/s", "cores": os.cpu_count(), "kind": "reference",
                                            "sample": f"failed: {e}"}
+                if args.cpu_table:
+                    out["cpu_baseline"]["table"] = cpu_table(w, h, spp)
         print(json.dumps(out), flush=True)
     if n > 1:
         dist.barrier()
