@@ -762,6 +762,31 @@ __device__ __forceinline__ bool start_sample(const R1TraceArgs &A, Path &p, uint
     return true;
 }
 
+// Path state in memory, [3][n] float4: {ox oy oz dx} {dy dz s_scalar s0} {s1 s2 k rays|depth<<8|sp<<16}
+// (0xFFFFFFFF in the last word marks a void sample slot).  Used by the wavefront variant.
+#define R1_PATH_VOID 0xFFFFFFFFu
+__device__ __forceinline__ void path_store(float4 *paths, const uint32_t n, const uint32_t slot, const Path &p)
+{
+    paths[slot] = make_float4(p.o.x, p.o.y, p.o.z, p.d.x);
+    paths[(size_t)n + slot] = make_float4(p.d.y, p.d.z, __uint_as_float(p.s_scalar), __uint_as_float(p.s0));
+    paths[2 * (size_t)n + slot] = make_float4(__uint_as_float(p.s1), __uint_as_float(p.s2), __uint_as_float(p.k),
+                                              __uint_as_float(p.rays | ((uint32_t)p.depth << 8) | ((uint32_t)p.sp << 16)));
+}
+
+// returns false for a void slot
+__device__ __forceinline__ bool path_load(const float4 *paths, const uint32_t n, const uint32_t slot, Path &p)
+{
+    const float4 a = paths[slot], b = paths[(size_t)n + slot], c = paths[2 * (size_t)n + slot];
+    p.o = mk(a.x, a.y, a.z);
+    p.d = mk(a.w, b.x, b.y);
+    p.s_scalar = __float_as_uint(b.z), p.s0 = __float_as_uint(b.w);
+    p.s1 = __float_as_uint(c.x), p.s2 = __float_as_uint(c.y);
+    p.k = __float_as_uint(c.z);
+    const uint32_t packed = __float_as_uint(c.w);
+    p.rays = packed & 255u, p.depth = (int)((packed >> 8) & 255u), p.sp = (int)((packed >> 16) & 255u);
+    return packed != R1_PATH_VOID;
+}
+
 // ---- one color() level after the hit test (rayweek1.cpp:517-534): count the ray, then either
 // scatter (new ray in p, hit index pushed on the attenuation stack) or finish the path: sky
 // colour times the stacked attenuations, or black.  Returns true when the path has ended, with
@@ -945,6 +970,9 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
             }
             const uint32_t avail = q_end - q_next;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            // (Generating the primary rays in a separate full-width kernel and loading them here was
+            // measured: 1.52 ms per frame against 1.28 — the extra launch per frame costs more overlap
+            // between frames than the refill saves.)
             if (!alive && rank < avail)
                 alive = start_sample(A, p, q_next + rank); // false: void slot, ask again
             q_next += min((uint32_t)__popcll(need), avail);
@@ -1079,26 +1107,6 @@ __device__ __forceinline__ void wave_append(uint32_t *counter, uint32_t *queue, 
         queue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
 }
 
-__device__ __forceinline__ void path_store(const R1WaveArgs &W, const uint32_t slot, const Path &p)
-{
-    W.paths[slot] = make_float4(p.o.x, p.o.y, p.o.z, p.d.x);
-    W.paths[(size_t)W.n_paths + slot] = make_float4(p.d.y, p.d.z, __uint_as_float(p.s_scalar), __uint_as_float(p.s0));
-    W.paths[2 * (size_t)W.n_paths + slot] = make_float4(__uint_as_float(p.s1), __uint_as_float(p.s2), __uint_as_float(p.k),
-                                                        __uint_as_float(p.rays | ((uint32_t)p.depth << 8) | ((uint32_t)p.sp << 16)));
-}
-
-__device__ __forceinline__ void path_load(const R1WaveArgs &W, const uint32_t slot, Path &p)
-{
-    const float4 a = W.paths[slot], b = W.paths[(size_t)W.n_paths + slot], c = W.paths[2 * (size_t)W.n_paths + slot];
-    p.o = mk(a.x, a.y, a.z);
-    p.d = mk(a.w, b.x, b.y);
-    p.s_scalar = __float_as_uint(b.z), p.s0 = __float_as_uint(b.w);
-    p.s1 = __float_as_uint(c.x), p.s2 = __float_as_uint(c.y);
-    p.k = __float_as_uint(c.z);
-    const uint32_t packed = __float_as_uint(c.w);
-    p.rays = packed & 255u, p.depth = (int)((packed >> 8) & 255u), p.sp = (int)((packed >> 16) & 255u);
-}
-
 } // namespace
 
 // sample slot k -> primary ray (rayweek1.cpp:759-760) in path slot k; void slots are skipped
@@ -1114,7 +1122,7 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_wf_generate(const R1WaveArgs W)
         if (k < W.n_paths)
             valid = start_sample(W.t, p, k);
         if (valid)
-            path_store(W, k, p);
+            path_store(W.paths, W.n_paths, k, p);
         wave_append(&W.counts[0], W.queue[0], valid, k);
     }
 }
@@ -1155,7 +1163,7 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_wf_shade(const R1WaveArgs W)
         {
             slot = q[i];
             Path p;
-            path_load(W, slot, p);
+            path_load(W.paths, W.n_paths, slot, p);
             const float2 h = W.hits[slot];
             V3 col;
             if (shade_level<true>(W.t, p, __float_as_int(h.y), h.x, nullptr, W.n_paths, slot, (int)threadIdx.x, col))
@@ -1165,7 +1173,7 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_wf_shade(const R1WaveArgs W)
             }
             else
             {
-                path_store(W, slot, p);
+                path_store(W.paths, W.n_paths, slot, p);
                 goes_on = true;
             }
         }
