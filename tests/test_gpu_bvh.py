@@ -276,3 +276,62 @@ def test_wavefront_variant_edges(renderer):
     with pytest.raises(binding.R1Error):  # the whole frame's paths must fit the workspace limit (2^24 slots)
         renderer.set_scene(r1.create_large_scene(4096, 4096))
         renderer.render(r1.make_params(4096, 4096, 2, 1, variant=binding.VARIANT_WAVEFRONT))
+
+
+# ---- randomised stress: many small scenes, tree vs the reference-form exhaustive kernel ---------------
+
+
+def test_bvh_random_scene_stress(renderer):
+    """40 random scenes (1..400 spheres; uniform, clustered, lattice-like and shell layouts; radii over
+    three decades; cameras inside and outside the cloud): the tree kernel must reproduce the
+    REFERENCE-form kernel (every sphere, reference arithmetic) on every sample."""
+    rng = np.random.default_rng(20261004)
+    w, h, spp = 48, 32, 2
+    base = r1.create_small_scene(w, h)
+    for trial in range(40):
+        n = int(rng.integers(1, 401))
+        layout = trial % 4
+        if layout == 0:
+            c = rng.uniform(-10, 10, (n, 3))
+        elif layout == 1:
+            c = rng.normal(0, 0.8, (n, 3)) + rng.uniform(-6, 6, (1, 3))
+        elif layout == 2:
+            g = int(np.ceil(np.sqrt(n)))
+            ij = np.stack(np.meshgrid(np.arange(g), np.arange(g)), -1).reshape(-1, 2)[:n]
+            c = np.concatenate([ij - g / 2 + rng.uniform(0, 0.9, (n, 2)), np.full((n, 1), 0.2)], 1)[:, [0, 2, 1]]
+        else:
+            u = rng.normal(0, 1, (n, 3))
+            c = u / np.linalg.norm(u, axis=1, keepdims=True) * rng.uniform(2, 9)
+        rad = np.exp(rng.uniform(np.log(3e-3), np.log(3.0), n))
+        if trial % 5 == 0:
+            rad[0], c[0] = 500.0, (0, -500.5, 0)  # a ground sphere
+        arr = spheres(c, rad, rng)
+        cam = base.camera_array().copy()
+        if trial % 3 == 0:  # camera in the middle of the cloud
+            shift = c.mean(0).astype(np.float32) - cam[0:3]
+            cam[0:3] += shift
+            cam[3:6] += shift
+        sa = r1o.SceneArrays(arr, cam)
+        renderer.set_scene_raw(_as_cscene(sa), _as_ccamera(sa))
+        got = renderer.render_samples(r1.make_params(w, h, spp, 1000 + trial, variant=BVH))
+        ref = renderer.render_samples(r1.make_params(w, h, spp, 1000 + trial, variant=binding.VARIANT_REFERENCE))
+        assert same(got, ref), (trial, n, layout)
+
+
+def test_bvh_300k_spheres_against_oracle_samples(renderer):
+    """A 640x480 lattice (307 204 spheres, beyond anything the exhaustive kernels finish quickly): the
+    tree kernel against the oracle's brute force on 120 pixel-samples, and determinism of the frame."""
+    w, h, spp = 128, 72, 2
+    sc = r1.create_grid_scene(w, h, 640, 480)
+    renderer.set_scene(sc)
+    a = renderer.render_samples(r1.make_params(w, h, spp, 77))
+    assert renderer.launch_info()["kernel"] == BVH and renderer.launch_info()["spheres_active"] == 640 * 480 + 4
+    b = renderer.render_samples(r1.make_params(w, h, spp, 77, tile_w=16, tile_h=8))
+    assert same(a, b)
+    sa = oracle_scene(sc)
+    rng = np.random.default_rng(3)
+    xs, ys, ss = rng.integers(0, w, 120), rng.integers(0, h, 120), rng.integers(0, spp, 120)
+    rgb, orays = r1o.trace_samples(sa, w, h, 77, xs, ys, ss)
+    got = a[2][(ys * w + xs) * spp + ss]
+    assert (got[:, 3].copy().view(np.uint32) == orays).all()
+    assert got[:, :3].tobytes() == rgb.tobytes()
