@@ -16,9 +16,11 @@
 // to the pad), and the point at its offered t lies within that distance + 5 u |v| of the
 // centre.  A child box is stored as centre m and half extent e; the kernel inflates it by
 //      pad = w2 * |m - o|^2 + k
-// with  w2 = 2 * (40 u * max_i 1 / (2 r_eff,i)) + 2^-20   and   k = w2 * h^2 + 2^-21 + ...,
-// h = max_i |c_i - m|, using |v|^2 <= 2 |m - o|^2 + 2 h^2.  The 2^-20 / 2^-21 terms cover the
-// rounding of the slab test itself (relative 3u of the distances involved, <= 2^-21 (1 + D^2)).
+// with  w2 = 2 * (40 u * max_i 1 / (2 r_eff,i)) + 2^-19   and   k = w2 * h^2 + 2^-20 + ...,
+// h = max_i |c_i - m|, using |v|^2 <= 2 |m - o|^2 + 2 h^2.  The 2^-19 / 2^-20 terms cover the
+// rounding of the slab test itself: products and differences (<= 6u D in position units, D the
+// largest distance involved) and the 1-ulp reciprocals of the direction (v_rcp_f32, <= 2^-22 D),
+// together < 2^-20.7 D <= 2^-21.7 (1 + D^2), against a budget of 2^-20 (1 + D^2).
 // Every constant is rounded up.  Extra visits are harmless: leaves apply the reference's rule.
 #include <hip/hip_runtime.h>
 
@@ -111,8 +113,8 @@ struct Builder
             h2 += hc * hc;
         }
         const double u = ldexp(1.0, -24);
-        w2 = 2.0 * (40.0 * u * bx.kmax) + ldexp(1.0, -20);
-        k = w2 * h2 + ldexp(1.0, -21) + 4.0 * u * bx.rmax + bx.floor_pad;
+        w2 = 2.0 * (40.0 * u * bx.kmax) + ldexp(1.0, -19);
+        k = w2 * h2 + ldexp(1.0, -20) + 4.0 * u * bx.rmax + bx.floor_pad;
     }
 
     uint32_t make_leaf(uint32_t b, uint32_t e)

@@ -574,7 +574,9 @@ __device__ __forceinline__ void sweep_bvh(const R1DeviceScene &S, const bool ali
     const float4 *__restrict__ nodes = S.bvh_nodes;
     const float4 *__restrict__ prims = S.bvh_prims;
     const uint32_t *__restrict__ ids = S.bvh_ids;
-    const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    // v_rcp_f32 (1 ulp) is enough here: the reciprocals only feed the conservative box test, whose
+    // pad budgets 2^-20 (|m - o|^2 + h^2) + 2^-20 for its own rounding (r1_bvh.cpp)
+    const V3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
     const f2 ox = splat2(o.x), oy = splat2(o.y), oz = splat2(o.z);
     const f2 ix = splat2(inv.x), iy = splat2(inv.y), iz = splat2(inv.z);
     const f2 jx = splat2(fabsf(inv.x)), jy = splat2(fabsf(inv.y)), jz = splat2(fabsf(inv.z));
@@ -886,10 +888,35 @@ __device__ __forceinline__ bool shade_level(const R1TraceArgs &A, Path &p, const
         const float omt = 1.0f - t;
         col = mk(omt * 1.0f + t * 0.5f, omt * 1.0f + t * 0.7f, omt * 1.0f + t * 1.0f);
         // unwind: attenuation * color(...) innermost first (rayweek1.cpp:525)
-        for (int e = p.sp - 1; e >= 0; --e)
+        if (BIG)
         {
-            const float4 sh = A.scene.shade[stack_get<BIG>(s_stack, A.gstack, gstride, gtid, tid, e)];
-            col = mk(sh.y * col.x, sh.z * col.y, sh.w * col.z);
+            for (int e = p.sp - 1; e >= 0; --e)
+            {
+                const float4 sh = A.scene.shade[stack_get<BIG>(s_stack, A.gstack, gstride, gtid, tid, e)];
+                col = mk(sh.y * col.x, sh.z * col.y, sh.w * col.z);
+            }
+        }
+        else if (p.sp > 0)
+        {
+            // packed stack: one LDS word holds entries 3w, 3w+1, 3w+2 (10 bits each); walk it word by
+            // word from the top entry down instead of dividing every entry index by 3
+            int w = (p.sp - 1) / 3, j = (p.sp - 1) - 3 * w;
+            for (; w >= 0; --w, j = 2)
+            {
+                const uint32_t v = s_stack[w * R1_BLOCK + tid];
+                if (j >= 2)
+                {
+                    const float4 sh = A.scene.shade[(v >> 20) & 0x3FFu];
+                    col = mk(sh.y * col.x, sh.z * col.y, sh.w * col.z);
+                }
+                if (j >= 1)
+                {
+                    const float4 sh = A.scene.shade[(v >> 10) & 0x3FFu];
+                    col = mk(sh.y * col.x, sh.z * col.y, sh.w * col.z);
+                }
+                const float4 sh = A.scene.shade[v & 0x3FFu];
+                col = mk(sh.y * col.x, sh.z * col.y, sh.w * col.z);
+            }
         }
         done = true;
     }

@@ -108,11 +108,13 @@ def ref_flagged(cx, cy, cz, rsq, o, d):
     return ok & ((t1 > F(0.001)) | (t2 > F(0.001)))
 
 
-def traverse(nodes, o, d):
+def traverse(nodes, o, d, jitter=None):
     """The kernel's visit rule without distance pruning: leaf slots the ray is shown."""
     o = o.astype(F)
     with np.errstate(divide="ignore", invalid="ignore"):
         inv = (F(1) / d.astype(F)).astype(F)
+        if jitter is not None:  # the kernel uses v_rcp_f32 (1 ulp): any reciprocal within one ulp must do
+            inv = np.where(np.isfinite(inv), np.nextafter(inv, np.where(jitter > 0, F(np.inf), F(-np.inf)).astype(F)), inv).astype(F)
         out = []
         stack = [0]
         while stack:
@@ -165,7 +167,7 @@ def test_traversal_rule_presents_every_sphere_the_reference_flags(kind):
         if q % 7 == 0:
             d = np.array([0, 0, -1], F) if q % 2 else np.array([1, 0, 0], F)  # axis-parallel: infinite reciprocals
         flagged = set(np.nonzero(ref_flagged(cx, cy, cz, rsq, o, d) & active)[0].tolist())
-        shown = set(ids[traverse(nodes, o, d)].tolist()) - {EMPTY}
+        shown = set(ids[traverse(nodes, o, d, rng.integers(0, 2, 3) * 2 - 1)].tolist()) - {EMPTY}
         assert flagged <= shown, (q, sorted(flagged - shown)[:5])
         shown_total += len(shown)
         flagged_total += len(flagged)
