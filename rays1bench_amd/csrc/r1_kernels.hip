@@ -94,7 +94,10 @@ __device__ __forceinline__ uint32_t xorshift32(uint32_t &state)
 }
 // mymath.h:27-35 and the x4 forms :41-73 — all exact: a 24-bit integer times a power of two
 __device__ __forceinline__ float rand01(uint32_t &s) { return (float)(xorshift32(s) & 0xFFFFFFu) * (1.0f / 16777216.0f); }
-__device__ __forceinline__ float rand02(uint32_t &s) { return (float)(xorshift32(s) & 0xFFFFFFu) * (1.0f / 8388608.0f); }
+// myrand02 - 1 (mymath.h:32-35, :58-73; used as `myrand02_x4(state) - Vec3(1,1,1)` :229 and in
+// random_in_unit_disk): the product with 2^-23 is exact, so the fused form rounds once, exactly
+// where the reference's subtraction rounds
+__device__ __forceinline__ float rand02_minus1(uint32_t &s) { return __fmaf_rn((float)(xorshift32(s) & 0xFFFFFFu), 1.0f / 8388608.0f, -1.0f); }
 
 template <bool BIG>
 struct IdxType
@@ -123,8 +126,7 @@ __device__ __forceinline__ V3 random_in_unit_sphere(Path &p)
     V3 r;
     do
     {
-        float a = rand02(p.s0), b = rand02(p.s1), c = rand02(p.s2);
-        r = vsub(mk(a, b, c), mk(1.0f, 1.0f, 1.0f));
+        r = mk(rand02_minus1(p.s0), rand02_minus1(p.s1), rand02_minus1(p.s2));
     } while (vdot(r, r) >= 1);
     return r;
 }
@@ -748,9 +750,9 @@ __device__ __forceinline__ bool start_sample(const R1TraceArgs &A, Path &p, uint
     V3 dk;
     do
     {
-        const float first = rand02(p.s_scalar);
-        const float second = rand02(p.s_scalar);
-        dk = vsub(mk(second, first, 0.0f), mk(1.0f, 1.0f, 0.0f));
+        const float first = rand02_minus1(p.s_scalar);
+        const float second = rand02_minus1(p.s_scalar);
+        dk = mk(second, first, 0.0f); // 2 * Vec3(rand, rand, 0) - Vec3(1, 1, 0): z = 0 - 0
     } while (vdot(dk, dk) >= 1.0f);
 
     // Camera::getRay (rayweek1.cpp:381-386)
