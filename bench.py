@@ -260,6 +260,30 @@ def main():
     value = rays_per_step * args.steps / elapsed / 1e6
     info = rend.launch_info()
 
+    # The same workload through the exhaustive sweep (the reference's algorithm: every ray against
+    # every sphere), when `value` came from the box tree: reported beside it, never instead of it.
+    sweep_line = None
+    if n == 1 and args.variant == 0 and info["kernel"] == 4 and args.emulate_shards <= 1 and info["spheres_active"] <= 1023:
+        p_main = p
+        p = r1.make_params(w, h, spp, args.seed, shard=0, num_shards=1, variant=binding.VARIANT_PREFILTER)
+        sweep_steps = max(len(slots), args.steps // 2)
+        for _ in range(len(slots)):
+            step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(sweep_steps):
+            step()
+        fence()
+        sweep_elapsed = time.perf_counter() - t1
+        sweep_line = {"value": rays_per_step * sweep_steps / sweep_elapsed / 1e6, "unit": "mrays/s", "steps": sweep_steps,
+                      "ms_per_step": sweep_elapsed / sweep_steps * 1e3,
+                      "kernel": "grouped exhaustive sweep (R1_VARIANT_PREFILTER): every ray tested against every sphere group, "
+                                "as the reference's Hitable::hit does; same pixels"}
+        p = p_main
+        slots[0].step()  # leave launch_info / images describing the main kernel
+        torch.cuda.synchronize()
+        info = rend.launch_info()
+
     # local rays of this rank for the roofline of ITS kernel launches
     local_rays = slots[0].local_rays()
 
@@ -329,6 +353,8 @@ def main():
                                           "tests the group tests stand for; aggregate over the timed region (all launches / "
                                           "elapsed); one isolated launch (--inflight 1): DESIGN.md §7"}},
         }
+        if sweep_line is not None:
+            out["exhaustive_sweep"] = sweep_line
         if check is not None:
             out["check"] = check
         if n == 1:
