@@ -157,6 +157,10 @@ RESULT benchmark(Scene *scene, Pix *pixels, bool write_tga, const char *scene_na
     printf("mrays/s:        %0.2f\n", result.get_mrays_per_sec());
     printf("devices:        %d (first hip:%d, %d CUs, %d workgroups x %d threads)\n", nd, g_device, li.compute_units, li.blocks,
            li.threads_per_block);
+    static const char *const kernel_names[] = {"default", "reference-form sweep", "grouped exhaustive sweep", "grouped exhaustive sweep + counters",
+                                               "box tree", "box tree + counters", "wavefront"};
+    printf("kernel:         %s (%d hittable spheres, %d inner nodes)\n", li.kernel >= 0 && li.kernel <= 6 ? kernel_names[li.kernel] : "?",
+           li.spheres_active, li.bvh_nodes);
     printf("device time:    %.3fms (%0.2f mrays/s)\n", device_seconds * 1e3, device_seconds ? result.num_rays / device_seconds / 1e6 : 0.0);
     printf("\n");
 
