@@ -5,6 +5,7 @@
 // entry point returns R1_ENODEVICE / R1_EHIP.
 
 #include <hip/hip_runtime.h>
+#include <cmath>
 
 #include <math.h>
 #include <stdarg.h>
@@ -369,6 +370,12 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
     for (uint32_t i = 0; i < s->count; ++i)
         if (s->inv_radius[i] != 0)
         {
+            // A sphere with a non-finite centre or radius_sq can never be hit by the reference's
+            // arithmetic (NaN/inf discriminant or roots fail every compare, rayweek1.cpp:204, :297-309):
+            // it is dropped here like a placeholder, which also keeps such values out of the tree builder.
+            if (!std::isfinite(s->center_x[i]) || !std::isfinite(s->center_y[i]) || !std::isfinite(s->center_z[i]) ||
+                !std::isfinite(s->radius_sq[i]))
+                continue;
             if (s->mat_type[i] > R1_MAT_DIELECTRIC)
             {
                 r1_set_error("r1_set_scene: sphere %u is hittable but has no material", i);

@@ -335,3 +335,22 @@ def test_bvh_300k_spheres_against_oracle_samples(renderer):
     got = a[2][(ys * w + xs) * spp + ss]
     assert (got[:, 3].copy().view(np.uint32) == orays).all()
     assert got[:, :3].tobytes() == rgb.tobytes()
+
+
+def test_non_finite_spheres_are_never_hit(renderer):
+    """NaN / inf centres or radius_sq among hittable spheres: the reference's arithmetic never hits them;
+    the product drops them at r1_set_scene.  Oracle (raw arithmetic) vs both kernel families."""
+    rng = np.random.default_rng(11)
+    w, h, spp = 64, 40, 3
+    n = 60
+    arr = spheres(rng.uniform(-3, 3, (n, 3)), rng.uniform(0.1, 0.5, n), rng)
+    arr["center_x"][3], arr["center_y"][7], arr["center_z"][11] = np.nan, np.inf, -np.inf
+    arr["radius_sq"][13], arr["radius_sq"][17] = np.inf, np.nan
+    sa = r1o.SceneArrays(arr, r1.create_small_scene(w, h).camera_array())
+    renderer.set_scene_raw(_as_cscene(sa), _as_ccamera(sa))
+    assert renderer.render(r1.make_params(w, h, spp, 2))[1] > w * h * spp
+    assert renderer.launch_info()["spheres_active"] == n - 5
+    oimg, orays, osamples = r1o.render_frame(sa, oparams(r1.make_params(w, h, spp, 2)), want_samples=True)
+    for v in (BVH, binding.VARIANT_PREFILTER, binding.VARIANT_REFERENCE):
+        got = renderer.render_samples(r1.make_params(w, h, spp, 2, variant=v))
+        assert got[1] == orays and got[2].tobytes() == osamples.tobytes(), v
