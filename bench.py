@@ -232,6 +232,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # setup, not warm-up: one frame through every slot so that its workspace (sample records,
+    # event ring) is allocated before anything is timed, whatever --warmup is
+    for sl in slots:
+        sl.step()
+    fence()
     for _ in range(args.warmup):
         step()
     fence()
