@@ -125,8 +125,8 @@ def cpu_baseline_grid(sc, w, h):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--scene", default="large", choices=list(SCENE_KIND))
     ap.add_argument("--width", type=int, default=1200)
     ap.add_argument("--height", type=int, default=800)
@@ -354,9 +354,14 @@ def main():
                                   "bound, so this fraction can exceed 1 and the binding roof is fp32 VALU issue"),
                          "valu": {"achieved_tflops": local_rays * 16.0 * n_pad * frames / elapsed / 1e12, "peak_tflops": FP32_VECTOR_PEAK_TF,
                                   "frac": local_rays * 16.0 * n_pad * frames / elapsed / 1e12 / FP32_VECTOR_PEAK_TF,
-                                  "note": "16 flop per ray-sphere test of the reference's sweep (SURVEY.md §8d), i.e. counting the sphere "
-                                          "tests the group tests stand for; aggregate over the timed region (all launches / "
-                                          "elapsed); one isolated launch (--inflight 1): DESIGN.md §7"}},
+                                  "note": ("reference-equivalent rate: 16 flop per ray-sphere test of the reference's sweep x N_pad "
+                                           "spheres per ray (SURVEY.md §8d) / elapsed.  The box tree presents ~6 spheres per ray, so this is "
+                                           "not work the kernel does; its own load is 0.76 G VALU wave-instructions per frame, ~88 % "
+                                           "VALU-issue busy (profiles/r01/pmc_counters_tree_kernel.json, DESIGN.md §4.4)")
+                                  if is_tree else
+                                          ("16 flop per ray-sphere test of the reference's sweep (SURVEY.md §8d), i.e. counting the sphere "
+                                           "tests the group tests stand for; aggregate over the timed region (all launches / "
+                                           "elapsed); one isolated launch (--inflight 1): DESIGN.md §7")}},
         }
         if sweep_line is not None:
             out["exhaustive_sweep"] = sweep_line
