@@ -434,18 +434,23 @@ __device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const bo
     }
     if (!BLOCK_SYNC)
     {
-        // Flags are kept as BITS, one per group, shifted into a per-lane word by the carry of the
-        // compare (v_cmp + v_addc: bits = 2 bits + flag): no branch, no per-flag bookkeeping in
-        // the sweep; a word goes to LDS every 32 groups and the wave works a batch of
-        // R1_BIT_WORDS words (256 groups) off at a time in cooperative_bits.
-#define R1_FLAG(QV, KS) asm volatile("v_cmp_le_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(QV), "s"(KS) : "vcc");
+        // Flags are kept as BITS, one per group, shifted into a per-lane word: no branch, no
+        // per-flag bookkeeping in the sweep; a word goes to LDS every 32 groups and the wave works a
+        // batch of R1_BIT_WORDS words (256 groups) off at a time in cooperative_bits.  The word
+        // collects the SIGN of q - Kp (one packed subtract per pair of groups + one v_alignbit_b32
+        // per group: bits = 2 bits + sign; 13.4 issue cycles per pair against 17.2 for v_cmp +
+        // v_addc, profiles/r01/isa_issue_costs.txt) and is inverted when stored: q >= Kp <=> the
+        // difference is not negative (a float difference has the exact sign; equal gives +0).
+#define R1_FLAG(RV) bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(RV), 31);
 #define R1_PAIR_BITS(L, B)                                                                                             \
     {                                                                                                                  \
         const v2f cx = {L[B + 0], L[B + 1]}, cy = {L[B + 2], L[B + 3]}, cz = {L[B + 4], L[B + 5]};                     \
         const v2f nb = __builtin_elementwise_fma(cz, dzz, __builtin_elementwise_fma(cy, dyy, __builtin_elementwise_fma(cx, dxx, nod))); \
         const v2f t = __builtin_elementwise_fma(cz, mzz, __builtin_elementwise_fma(cy, myy, __builtin_elementwise_fma(cx, mxx, ooa))); \
         const v2f q = __builtin_elementwise_fma(nb, nb, -t);                                                           \
-        R1_FLAG(q.x, L[B + 6]) R1_FLAG(q.y, L[B + 7])                                                                  \
+        const v2f kp = {L[B + 6], L[B + 7]};                                                                           \
+        const v2f r = q - kp;                                                                                          \
+        R1_FLAG(r.x) R1_FLAG(r.y)                                                                                      \
     }
 #define R1_CHUNK_BITS(L0, L1) {R1_PAIR_BITS(L0, 0) R1_PAIR_BITS(L0, 8) R1_PAIR_BITS(L1, 0) R1_PAIR_BITS(L1, 8)}
         uint32_t bits = 0;
@@ -468,7 +473,7 @@ __device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const bo
             R1_CHUNK_BITS(b0, b1)
             if (ch & 2u) // 32 groups since the last word
             {
-                cand[nwords * R1_BLOCK + tid] = bits;
+                cand[nwords * R1_BLOCK + tid] = ~bits;
                 if (++nwords == R1_BIT_WORDS)
                 {
                     cooperative_bits<STATS, IDX>(S, o, d, nwords, gbase, cand, wpairs, wbest, tid, lane, wstat);
@@ -484,7 +489,7 @@ __device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const bo
         }
         if (ch & 3u) // a partial word: left-align it
         {
-            cand[nwords * R1_BLOCK + tid] = bits << (32u - 8u * (ch & 3u));
+            cand[nwords * R1_BLOCK + tid] = ~bits << (32u - 8u * (ch & 3u));
             ++nwords;
         }
         if (STATS)
