@@ -143,3 +143,26 @@ def test_rayweek1_hip_fails_loudly_without_gpu(tmp_path):
     assert out.returncode == 2
     assert b"cannot create HIP context" in out.stderr
     assert not os.path.exists(tmp_path / "out_large.txt")
+
+
+def test_headers_are_plain_c99_and_link_against_the_library(tmp_path):
+    """The drop-in boundary is a C ABI: include/*.h must compile as strict C99 (no C++ or torch types)
+    and a C program must link against librays1.so and reach a host-only entry point."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "rays1.h"\n#include "rays1_seed.h"\n#include <stdio.h>\n'
+                   'int main(void) {\n'
+                   '    r1_params p = {64, 32, 1, 50, 1, 32, 32, 0, 1, R1_VARIANT_DEFAULT};\n'
+                   '    int32_t total = 0, per = 0;\n'
+                   '    if (r1_abi_version() != R1_ABI_VERSION || r1_tile_count(&p, &total, &per) != R1_OK) return 1;\n'
+                   '    r1_sample_seed s = r1_seed_sample(10001u, 7u, 3u);\n'
+                   '    printf("%d %d %u\\n", (int)total, (int)per, (unsigned)s.scalar);\n'
+                   '    return 0;\n}\n')
+    exe = tmp_path / "abi"
+    libdir = os.path.join(ROOT, "rays1bench_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lrays1", f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined"])
+    out = subprocess.run([str(exe)], capture_output=True, timeout=60)
+    assert out.returncode == 0, out.stderr.decode()
+    total, per, scalar = out.stdout.decode().split()
+    assert (int(total), int(per)) == (2, 2) and int(scalar) != 0
