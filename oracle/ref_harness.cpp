@@ -513,6 +513,128 @@ static int cmd_kat(int argc, const char **argv)
     return 0;
 }
 
+#ifdef R1_DROPIN
+// ------------------------------------------------------------------------------------
+// The binding of INTEGRATION.md, for real: the reference's OWN Scene object (create_*_scene of
+// rayweek1.cpp, untouched) is handed to librays1.so through the C-ABI exactly as a maintainer's
+// benchmark() would do it — the SoA arrays are passed in place (soa_sphere.h:38-53), only the
+// polymorphic material column is flattened — and the same frame is rendered by the reference's
+// own TileRenderScheduler on the host cores.  Output: one JSON line.  (Needs a GPU at run time;
+// built here because only this container has the reference sources.)
+#include "../include/rays1.h"
+
+static uint64_t fnv1a(const uint8_t *p, size_t n)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i)
+        h = (h ^ p[i]) * 1099511628211ull;
+    return h;
+}
+
+static int cmd_dropin(int argc, const char **argv)
+{
+    // dropin <scene> <w> <h> <spp> <seed> <variant> [out.bin]
+    if (argc < 6)
+        return 1;
+    const SceneDesc *d = find_scene(argv[0]);
+    const int w = atoi(argv[1]), h = atoi(argv[2]), spp = atoi(argv[3]);
+    const uint32_t seed = (uint32_t)strtoul(argv[4], 0, 10);
+    const int variant = atoi(argv[5]);
+    Scene *scene = make_scene(d, w, h);
+    const SphereSOA::InstanceData *s = scene->hitables->_soa_spheres.getData();
+    const uint32_t n = s->_count;
+
+    Lambertian l(Vec3(0, 0, 0));
+    Metal m(Vec3(0, 0, 0), 0);
+    Dielectric g(1);
+    void *vl = *(void **)&l, *vm = *(void **)&m, *vg = *(void **)&g;
+    std::vector<uint8_t> type(n, 255);
+    std::vector<float> ar(n, 0), ag(n, 0), ab(n, 0), par(n, 0);
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        Material *mat = s->material[i];
+        if (!mat)
+            continue;
+        void *v = *(void **)mat;
+        Vec3 a(1, 1, 1);
+        if (v == vl)
+            type[i] = R1_MAT_LAMBERTIAN, a = ((Lambertian *)mat)->albedo;
+        else if (v == vm)
+            type[i] = R1_MAT_METAL, a = ((Metal *)mat)->albedo, par[i] = ((Metal *)mat)->fuzz;
+        else if (v == vg)
+            type[i] = R1_MAT_DIELECTRIC, par[i] = ((Dielectric *)mat)->_refIdx;
+        ar[i] = a.getX(), ag[i] = a.getY(), ab[i] = a.getZ();
+    }
+    r1_scene rs = {n, s->center_x, s->center_y, s->center_z, s->radius_sq, s->inv_radius, type.data(), ar.data(), ag.data(), ab.data(), par.data()};
+    r1_camera rc;
+    vec3_out(rc.origin, scene->camera._origin);
+    vec3_out(rc.lower_left, scene->camera._lowerLeftCorner);
+    vec3_out(rc.horizontal, scene->camera._horizontal);
+    vec3_out(rc.vertical, scene->camera._vertical);
+    vec3_out(rc.u, scene->camera._u);
+    vec3_out(rc.v, scene->camera._v);
+    vec3_out(rc.w, scene->camera._w);
+    rc.lens_radius = scene->camera._lensRadius;
+
+    r1_context *ctx = 0;
+    if (r1_create(0, &ctx) != R1_OK || r1_set_scene(ctx, &rs, &rc) != R1_OK)
+    {
+        fprintf(stderr, "dropin: %s\n", r1_last_error());
+        return 6;
+    }
+    r1_params p = {w, h, spp, MAX_BOUNCES, seed, 32, 32, 0, 1, variant};
+    std::vector<Pix> gpu_pixels((size_t)w * h), cpu_pixels((size_t)w * h);
+    uint64_t gpu_rays = 0;
+    double device_seconds = 0;
+    Timer tg;
+    if (r1_render(ctx, &p, &gpu_pixels[0].r, &gpu_rays, &device_seconds) != R1_OK)
+    {
+        fprintf(stderr, "dropin: %s\n", r1_last_error());
+        return 6;
+    }
+    const double gpu_elapsed = tg.elapsed();
+    r1_destroy(ctx);
+
+    // the reference's own multi-threaded path on the same Scene object (rayweek1.cpp:851-877)
+    Timer tc;
+    ThreadData td;
+    memset(&td, 0, sizeof(td));
+    td.scene = scene;
+    td.image = cpu_pixels.data();
+    td.image_w = w;
+    td.image_h = h;
+    td.tile_w_in_pixels = 32 > w ? w : 32;
+    td.tile_h_in_pixels = 32 > h ? h : 32;
+    td.samples_per_pixel = spp;
+    const int num_tiles = tiles_required(td.tile_w_in_pixels, w) * tiles_required(td.tile_h_in_pixels, h);
+    TileRenderScheduler scheduler;
+    const int threads = (int)std::thread::hardware_concurrency();
+    const uint64_t cpu_rays = scheduler.run(num_tiles, threads, &td);
+    const double cpu_elapsed = tc.elapsed();
+
+    double gsum = 0, csum = 0, adiff = 0;
+    const uint8_t *gp = &gpu_pixels[0].r, *cp = &cpu_pixels[0].r;
+    for (size_t i = 0; i < (size_t)w * h * 3; ++i)
+        gsum += gp[i], csum += cp[i], adiff += fabs((double)gp[i] - (double)cp[i]);
+    const double npx = (double)w * h * 3;
+    printf("{\"scene\": \"%s\", \"w\": %d, \"h\": %d, \"spp\": %d, \"seed\": %u, \"variant\": %d, \"spheres\": %u, "
+           "\"gpu_rays\": %llu, \"gpu_image_fnv1a\": \"%016llx\", \"gpu_image_mean\": %.6f, \"gpu_seconds\": %.6f, \"gpu_device_seconds\": %.6f, "
+           "\"ref_cpu_rays\": %llu, \"ref_cpu_image_mean\": %.6f, \"ref_cpu_seconds\": %.6f, \"ref_cpu_threads\": %d, "
+           "\"mean_abs_pixel_difference\": %.6f}\n",
+           d->name, w, h, spp, seed, variant, n, (unsigned long long)gpu_rays, (unsigned long long)fnv1a(gp, (size_t)w * h * 3), gsum / npx,
+           gpu_elapsed, device_seconds, (unsigned long long)cpu_rays, csum / npx, cpu_elapsed, threads, adiff / npx);
+    if (argc > 6)
+    {
+        Writer wr(argv[6]);
+        uint32_t hdr[3] = {(uint32_t)w, (uint32_t)h, (uint32_t)spp};
+        wr.u32("hdr", hdr, 3);
+        wr.u8("image", gp, (size_t)w * h * 3);
+    }
+    delete scene;
+    return 0;
+}
+#endif
+
 int main(int argc, const char **argv)
 {
     if (argc < 2)
@@ -534,6 +656,10 @@ int main(int argc, const char **argv)
         rc = cmd_bench(argc - 2, argv + 2);
     else if (!strcmp(cmd, "kat"))
         rc = cmd_kat(argc - 2, argv + 2);
+#ifdef R1_DROPIN
+    else if (!strcmp(cmd, "dropin"))
+        rc = cmd_dropin(argc - 2, argv + 2);
+#endif
     if (rc == 1)
         fprintf(stderr, "bad arguments for '%s'\n", cmd);
     return rc;
