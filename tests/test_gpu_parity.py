@@ -509,9 +509,10 @@ def test_grouped_prefilter_is_exact_on_random_scenes(renderer, case):
 # ---- INTEGRATION.md's binding, compiled against the real reference ---------------------------------
 
 
-def test_reference_scene_object_through_the_c_abi():
+@pytest.mark.parametrize("name,count", [("small", 8), ("medium", 48), ("large", 488)])
+def test_reference_scene_object_through_the_c_abi(name, count):
     """oracle/_ref/ref_step13_dropin (built in the container that has the reference sources) hands the
-    reference's OWN Scene object — create_large_scene() of rayweek1.cpp, SoA arrays in place, materials
+    reference's OWN Scene objects — create_small/medium/large_scene() of rayweek1.cpp, SoA arrays in place, materials
     flattened — to librays1.so through the C-ABI, and renders the same frame with the reference's own
     TileRenderScheduler on the host.  The GPU frame must equal what this repo's scene builders give
     for the same parameters (same arrays => same pixels), and agree statistically with the
@@ -523,19 +524,19 @@ def test_reference_scene_object_through_the_c_abi():
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/ref_step13_dropin not built (needs the reference sources at build time)")
     w, h, spp, seed = 1200, 800, 10, 10001
-    out = subprocess.run([exe, "dropin", "large", str(w), str(h), str(spp), str(seed), "0"], capture_output=True, timeout=600)
+    out = subprocess.run([exe, "dropin", name, str(w), str(h), str(spp), str(seed), "0"], capture_output=True, timeout=600)
     assert out.returncode == 0, out.stderr.decode()
     rec = json.loads(out.stdout.decode().strip().splitlines()[-1])
     rend = r1.Renderer(0)
     try:
-        rend.set_scene(r1.create_large_scene(w, h))
+        rend.set_scene(MAKE[name](w, h))
         img, rays, _ = rend.render(r1.make_params(w, h, spp, seed))
     finally:
         rend.close()
     fnv = 1469598103934665603
     for b in img.tobytes():
         fnv = ((fnv ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
-    assert rec["spheres"] == 488
+    assert rec["spheres"] == count
     assert rec["gpu_rays"] == rays
     assert int(rec["gpu_image_fnv1a"], 16) == fnv
     assert abs(rec["gpu_rays"] - rec["ref_cpu_rays"]) <= 1e-3 * rec["ref_cpu_rays"]
