@@ -176,3 +176,49 @@ def test_traversal_rule_presents_every_sphere_the_reference_flags(kind):
     if kind != "far_tiny":
         assert shown_total < 0.2 * n_rays * active.sum()
     assert flagged_total > 0
+
+
+def _raw_scene(c, rad):
+    """CScene over numpy arrays (kept alive by the returned tuple)."""
+    import ctypes as C
+    c = np.asarray(c, F)
+    rad = np.asarray(rad, F)
+    n = len(rad)
+    arrs = {"center_x": c[:, 0].copy(), "center_y": c[:, 1].copy(), "center_z": c[:, 2].copy(), "radius_sq": (rad * rad).astype(F),
+            "inv_radius": (F(1) / rad).astype(F), "albedo_r": np.full(n, 0.5, F), "albedo_g": np.full(n, 0.5, F),
+            "albedo_b": np.full(n, 0.5, F), "mat_param": np.zeros(n, F)}
+    mt = np.zeros(n, np.uint8)
+    cs = binding.CScene()
+    cs.count = n
+    for k, v in arrs.items():
+        setattr(cs, k, v.ctypes.data_as(C.POINTER(C.c_float)))
+    cs.mat_type = mt.ctypes.data_as(C.POINTER(C.c_uint8))
+    return cs, arrs, mt
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scenes_tree_invariants_and_visit_rule(seed):
+    """Random clouds (1..600 spheres, radii over four decades, duplicates, one huge sphere now and then):
+    structure invariants, depth bound, and the visit rule against brute force for 60 rays each."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1, 601))
+    c = rng.normal(0, rng.uniform(0.5, 20), (n, 3))
+    rad = np.exp(rng.uniform(np.log(1e-3), np.log(10.0), n))
+    if seed % 3 == 0 and n > 4:
+        c[: n // 4] = c[0]                       # coincident centres
+    if seed % 4 == 0:
+        rad[-1], c[-1] = 2000.0, (0, -2001, 0)   # a ground sphere
+    cs, arrs, mt = _raw_scene(c, rad)
+    info, nodes, ids = binding.bvh_describe(cs)
+    real = ids[ids != EMPTY]
+    assert sorted(real.tolist()) == list(range(n))
+    assert 1 <= info["depth"] <= info["stack_entries"]
+    cx, cy, cz, rsq = arrs["center_x"], arrs["center_y"], arrs["center_z"], arrs["radius_sq"]
+    for q in range(60):
+        o = (rng.normal(0, 1, 3) * rng.choice([1.0, 30.0, 400.0])).astype(F)
+        target = c[rng.integers(0, n)] + rng.normal(0, 1, 3) * rad.mean()
+        d = (target - o).astype(np.float64)
+        d = (d / np.linalg.norm(d)).astype(F)
+        flagged = set(np.nonzero(ref_flagged(cx, cy, cz, rsq, o, d))[0].tolist())
+        shown = set(ids[traverse(nodes, o, d, rng.integers(0, 2, 3) * 2 - 1)].tolist()) - {EMPTY}
+        assert flagged <= shown, (seed, q, sorted(flagged - shown)[:5])
