@@ -10,7 +10,8 @@
 #define R1_CAND_CAP 16      // big scenes: per-lane flagged-group slots in LDS (flushed when a lane passes CAP-8)
 #define R1_PAIR_CAP 1024    // (lane, sphere) pairs of one wave: 64 lanes x R1_CAND_CAP
 #define R1_STACK_WORDS 17   // ceil(51 / 3) packed 10-bit hit indices per lane (max_bounces <= 51)
-#define R1_CHUNK 256        // most samples a wave takes from the global queue per atomic
+#define R1_CHUNK 256        // most samples a wave takes from the global queue per atomic (small frames) ...
+#define R1_CHUNK_BIG 1024   // ... growing with a wave's share of the frame up to this (enqueue_frame)
 #define R1_CHUNK_MIN 32      // fewest (end of the queue: guided self-scheduling)
 #define R1_GROUP_MAX 4         // spheres per group (level 1 of the sweep tests group bounds)
 #define R1_GROUP_MIN_SPHERES 128 // scenes with fewer active spheres are swept ungrouped
@@ -86,6 +87,7 @@ struct R1TraceArgs
     uint32_t full;               // tile_w * tile_h * spp slots per local tile
     R1FastDiv div_full, div_spp, div_tw, div_tx; // by full, spp, tile_w, tiles_x
     uint32_t total_samples;      // n_local_tiles * full (queue length)
+    uint32_t chunk_min, chunk_max; // samples a wave takes from the queue per atomic (guided: remaining / (2 waves), clamped)
     uint32_t *queue;             // global sample counter (zeroed before the launch)
     float4 *samples;             // [total_samples] {r, g, b, bit_cast<float>(rays)}
     unsigned long long *num_rays; // accumulated color() invocations

@@ -988,7 +988,7 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
             {
                 if (exhausted)
                     break;
-                const uint32_t want = min((uint32_t)R1_CHUNK, max((uint32_t)R1_CHUNK_MIN, q_remaining / n_waves2));
+                const uint32_t want = min(A.chunk_max, max(A.chunk_min, q_remaining / n_waves2));
                 uint32_t base = 0;
                 if (lane == 0)
                     base = atomicAdd(A.queue, want);
