@@ -151,7 +151,9 @@ def main():
     # Frames in flight only overlap when their streams sit on different hardware queues; the
     # ROCm default is 4 (measured: 16 queues + 16 frames in flight reach 98 % / 91 % of the ideal
     # per-rank frame time at 1/2/4 and 8 shards, 4 queues 78 % / 66 %).  Must be set before HIP starts.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    # One queue per frame in flight: streams that share a queue serialise, and spare queues hurt too
+    # (measured: 16 in flight on 16 queues 1.18 ms per frame; 12 on 16: 1.77; 12 on 12: 1.20; 24 on 24: 1.53).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(1, min(args.inflight, 24))))
     import torch
     import rays1bench_amd as r1
     from rays1bench_amd import binding, sharding
