@@ -53,8 +53,11 @@ enum
  * polymorphic `Material*` column replaced by a flat material table.  `count` includes
  * the reference's padding placeholders (centre 1e9, inv_radius 0); spheres with
  * inv_radius == 0 (placeholders AND non-positive radii, soa_sphere.cpp:81) are never
- * hit, exactly as rayweek1.cpp:291.  All arrays are host memory, length `count`,
- * owned by the caller and only read during the call they are passed to. */
+ * hit, exactly as rayweek1.cpp:291 (and so are spheres with a non-finite centre or
+ * radius_sq, which the reference's arithmetic can never hit).  `radius_sq[i]` and
+ * `inv_radius[i]` must belong to the same radius, as SphereSOA::add stores them
+ * (soa_sphere.cpp:70-85).  All arrays are host memory, length `count`, owned by the
+ * caller and only read during the call they are passed to. */
 typedef struct r1_scene
 {
     uint32_t count;
@@ -107,7 +110,8 @@ enum
     R1_VARIANT_DEFAULT = 0,   /* fastest validated kernel for the scene: BVH, except PREFILTER for 9..127 hittable spheres */
     R1_VARIANT_REFERENCE = 1, /* pass 1 in the reference's exact arithmetic (rayweek1.cpp:190-202),
                                  no prefilter; slower, used to cross-check the default       */
-    R1_VARIANT_PREFILTER = 2, /* conservative 8-op prefilter + exact re-test */
+    R1_VARIANT_PREFILTER = 2, /* the exhaustive sweep (every ray against every sphere, as Hitable::hit does,
+                                 rayweek1.cpp:182-322): conservative grouped prefilter + exact re-test */
     R1_VARIANT_STATS = 3,     /* PREFILTER plus in-kernel phase/utilisation counters (diagnostic; r1_last_stats) */
     R1_VARIANT_BVH = 4,       /* optional spatial index (the reference has none, README.md:163): a conservative
                                  box tree chooses the spheres given to the reference's per-sphere test; results
