@@ -10,6 +10,7 @@
 //
 // What the reference fixes at compile time (common.h:19-28) is a run-time option here:
 //     --width W --height H --spp S --seed N --device D --devices N --variant V
+//       (V = R1_VARIANT_*: 0 default, 1 reference-form sweep, 2 exhaustive sweep, 4 box tree, 6 wavefront)
 // Defaults are the reference's multi-threaded defaults: 1280x720, 250 spp.
 // --devices N splits the frame over N HIP devices inside this one process (one host thread
 // and one r1_context per device, tile t -> device t % N, each device writes its own tiles of
