@@ -8,7 +8,8 @@
 #define R1_BLOCK 256        // threads per workgroup = 4 wave64
 #define R1_BIT_WORDS 8      // small scenes: per-lane flag words in LDS, 32 groups each, worked off 256 groups at a time
 #define R1_CAND_CAP 16      // big scenes: per-lane flagged-group slots in LDS (flushed when a lane passes CAP-8)
-#define R1_PAIR_CAP 1024    // (lane, sphere) pairs of one wave: 64 lanes x R1_CAND_CAP
+#define R1_PAIR_CAP 1024    // (lane, sphere) pairs of one wave, big scenes: 64 lanes x R1_CAND_CAP
+#define R1_PAIR_CAP_SMALL 512 // same, small scenes (bit path): 4 KB less LDS per workgroup = a fifth workgroup per CU
 #define R1_STACK_WORDS 17   // ceil(51 / 3) packed 10-bit hit indices per lane (max_bounces <= 51)
 #define R1_CHUNK 256        // most samples a wave takes from the global queue per atomic (small frames) ...
 #define R1_CHUNK_BIG 1024   // ... growing with a wave's share of the frame up to this (enqueue_frame)

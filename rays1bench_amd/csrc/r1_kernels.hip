@@ -231,6 +231,7 @@ template <typename IDX>
 struct PairBits
 {
     static constexpr int value = sizeof(IDX) == 2 ? 10 : 26;
+    static constexpr int cap = sizeof(IDX) == 2 ? R1_PAIR_CAP_SMALL : R1_PAIR_CAP; // pairs of one wave
 };
 
 __device__ __forceinline__ int wave_inclusive_scan(int v, const int lane)
@@ -324,10 +325,11 @@ __device__ __forceinline__ void cooperative_bits(const R1DeviceScene &S, const V
         wstat[9] += (unsigned long long)((cnt & 0xFFFF) + (cnt >> 16));
     if (totals == 0)
         return;
-    if (total_m + total_s <= R1_PAIR_CAP)
+    constexpr int CAP = PairBits<IDX>::cap;
+    if (total_m + total_s <= CAP)
     {
         int pos_m = (incl - cnt) & 0xFFFF;
-        int pos_s = R1_PAIR_CAP - 1 - ((incl - cnt) >> 16); // singles grow down from the end
+        int pos_s = CAP - 1 - ((incl - cnt) >> 16); // singles grow down from the end
         for (uint32_t w = 0; w < nwords; ++w)
         {
             uint32_t word = words[w * R1_BLOCK + tid];
@@ -345,13 +347,16 @@ __device__ __forceinline__ void cooperative_bits(const R1DeviceScene &S, const V
         }
         __builtin_amdgcn_wave_barrier();
         exact_trips<STATS, IDX, R1_GROUP_MAX>(S, o, d, total_m, pairs, best, lane, wstat);
-        exact_trips<STATS, IDX, 1>(S, o, d, total_s, pairs + (R1_PAIR_CAP - total_s), best, lane, wstat);
+        exact_trips<STATS, IDX, 1>(S, o, d, total_s, pairs + (CAP - total_s), best, lane, wstat);
         return;
     }
-    for (uint32_t seg = 0; seg < 2u * nwords; ++seg)
+    // more pairs than the list holds: work the flag words off in segments of CAP / 64 bits, whose
+    // flags always fit (64 lanes x SEG bits)
+    constexpr uint32_t SEG = (uint32_t)CAP / 64u, PER_WORD = 32u / SEG;
+    for (uint32_t seg = 0; seg < PER_WORD * nwords; ++seg)
     {
-        const uint32_t w = seg >> 1;
-        uint32_t word = words[w * R1_BLOCK + tid] & ((seg & 1u) ? 0x0000FFFFu : 0xFFFF0000u);
+        const uint32_t w = seg / PER_WORD, part = seg - w * PER_WORD;
+        uint32_t word = words[w * R1_BLOCK + tid] & (((1u << SEG) - 1u) << (32u - SEG * (part + 1u)));
         const int c2 = __popc(word);
         const int incl2 = wave_inclusive_scan(c2, lane);
         const int total2 = __builtin_amdgcn_readlane(incl2, 63);
@@ -378,7 +383,7 @@ __device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const bo
                                                 const int tid, unsigned long long *wstat)
 {
     const int lane = tid & 63;
-    IDX *wpairs = pairs + (tid >> 6) * R1_PAIR_CAP;
+    IDX *wpairs = pairs + (tid >> 6) * PairBits<IDX>::cap;
     unsigned long long *wbest = best + (tid & ~63);
     const unsigned long long NONE = ~0ull;
 
@@ -951,7 +956,7 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
     }
     __shared__ uint32_t s_stack[BIG ? 1 : R1_STACK_WORDS * R1_BLOCK];
     __shared__ uint32_t s_cand[VARIANT == 2 ? (BIG ? R1_CAND_CAP : R1_BIT_WORDS) * R1_BLOCK : 1];
-    __shared__ IDX s_pairs[VARIANT == 2 ? (R1_BLOCK / 64) * R1_PAIR_CAP : 1];
+    __shared__ IDX s_pairs[VARIANT == 2 ? (R1_BLOCK / 64) * PairBits<IDX>::cap : 1];
     // R1_VARIANT_BVH: traversal stack [tree depth][thread], sized at launch (dynamic LDS)
     extern __shared__ uint32_t s_trav[];
     const uint32_t gstride = gridDim.x * R1_BLOCK, gtid = blockIdx.x * R1_BLOCK + threadIdx.x;
