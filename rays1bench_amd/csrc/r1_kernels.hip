@@ -566,19 +566,28 @@ __device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const bo
 // the reference's in-order rule (see exact_offer).  The traversal stack lives in LDS,
 // [entry][thread]; the builder bounds the tree depth by R1_BVH_STACK.
 #define R1_BVH_DONE 0xFFFFFFFFu
-typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2 splat2(const float v)
-{
-    f2 r = {v, v};
-    return r;
-}
-__device__ __forceinline__ f2 fma2(const f2 a, const f2 b, const f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 // STATS (diagnostic build): wstat[2] wave trips of the node loop, [3] wave trips of the leaf
 // pair loop, [9] node visits summed over lanes, [5] sphere-pair tests summed over lanes.
-// Both children of a node, and both spheres of a leaf pair, go through the arithmetic side by
-// side in the two halves of packed fp32 instructions (v_pk_add/mul/fma_f32: IEEE per half, so a
-// sphere's numbers are exactly those of exact_offer).
+// One child box {m, e} inflated by pad = w2 |m - o|^2 + k against the ray.  Scalar arithmetic on
+// purpose: the packed form (both children per v_pk_* instruction) costs the same issue cycles on
+// this chip (profiles/r01/isa_issue_costs.txt) but 13 more VGPRs, and the kernel's register count
+// sits right at the limit for 6 waves per SIMD.
+__device__ __forceinline__ bool bvh_box(const float mx, const float my, const float mz, const float ex, const float ey, const float ez,
+                                        const float w2, const float k, const V3 o, const V3 inv, const V3 ainv, const float best, float &t_near)
+{
+    const float cx = mx - o.x, cy = my - o.y, cz = mz - o.z;
+    const float d2 = __fmaf_rn(cz, cz, __fmaf_rn(cy, cy, cx * cx));
+    const float pad = __fmaf_rn(w2, d2, k);
+    const float ax = cx * inv.x, ay = cy * inv.y, az = cz * inv.z;
+    const float bx = (ex + pad) * ainv.x, by = (ey + pad) * ainv.y, bz = (ez + pad) * ainv.z;
+    // NaN (0 x inf on an axis the ray does not move along) drops out of fmaxf/fminf: no constraint
+    const float tn = fmaxf(fmaxf(ax - bx, ay - by), az - bz);
+    const float tf = fminf(fminf(ax + bx, ay + by), az + bz);
+    t_near = tn;
+    return tn <= fminf(tf, best) && tf >= 0.0f;
+}
+
 template <bool STATS>
 __device__ __forceinline__ void sweep_bvh(const R1DeviceScene &S, const bool alive, const V3 o, const V3 d, float &t_max, int &hit_index,
                                           uint32_t *trav, const int tid, unsigned long long *wstat)
@@ -587,12 +596,9 @@ __device__ __forceinline__ void sweep_bvh(const R1DeviceScene &S, const bool ali
     const float4 *__restrict__ prims = S.bvh_prims;
     const uint32_t *__restrict__ ids = S.bvh_ids;
     // v_rcp_f32 (1 ulp) is enough here: the reciprocals only feed the conservative box test, whose
-    // pad budgets 2^-20 (|m - o|^2 + h^2) + 2^-20 for its own rounding (r1_bvh.cpp)
+    // pad budgets 2^-19 (|m - o|^2 + h^2) + 2^-20 for its own rounding (r1_bvh.cpp)
     const V3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-    const f2 ox = splat2(o.x), oy = splat2(o.y), oz = splat2(o.z);
-    const f2 ix = splat2(inv.x), iy = splat2(inv.y), iz = splat2(inv.z);
-    const f2 jx = splat2(fabsf(inv.x)), jy = splat2(fabsf(inv.y)), jz = splat2(fabsf(inv.z));
-    const f2 dx = splat2(d.x), dy = splat2(d.y), dz = splat2(d.z);
+    const V3 ainv = mk(fabsf(inv.x), fabsf(inv.y), fabsf(inv.z));
     float best = FLT_MAX;
     uint32_t best_id = 0xFFFFFFFFu;
     uint32_t cur = alive ? 0u : R1_BVH_DONE;
@@ -611,20 +617,9 @@ __device__ __forceinline__ void sweep_bvh(const R1DeviceScene &S, const bool ali
             // {m0x m1x m0y m1y} {m0z m1z e0x e1x} {e0y e1y e0z e1z} {w2 k child0 child1}
             const float4 q0 = nodes[4 * (size_t)cur + 0], q1 = nodes[4 * (size_t)cur + 1], q2 = nodes[4 * (size_t)cur + 2],
                          q3 = nodes[4 * (size_t)cur + 3];
-            const f2 mx = {q0.x, q0.y}, my = {q0.z, q0.w}, mz = {q1.x, q1.y};
-            const f2 ex = {q1.z, q1.w}, ey = {q2.x, q2.y}, ez = {q2.z, q2.w};
-            const f2 cx = mx - ox, cy = my - oy, cz = mz - oz;
-            const f2 d2 = fma2(cz, cz, fma2(cy, cy, cx * cx));
-            const f2 pad = fma2(splat2(q3.x), d2, splat2(q3.y));
-            const f2 ax = cx * ix, ay = cy * iy, az = cz * iz;
-            const f2 bx = (ex + pad) * jx, by = (ey + pad) * jy, bz = (ez + pad) * jz;
-            const f2 lx = ax - bx, ly = ay - by, lz = az - bz;
-            const f2 hx = ax + bx, hy = ay + by, hz = az + bz;
-            // NaN (0 x inf on an axis the ray does not move along) drops out of fmaxf/fminf: no constraint
-            const float tn0 = fmaxf(fmaxf(lx.x, ly.x), lz.x), tn1 = fmaxf(fmaxf(lx.y, ly.y), lz.y);
-            const float tf0 = fminf(fminf(hx.x, hy.x), hz.x), tf1 = fminf(fminf(hx.y, hy.y), hz.y);
-            const bool h0 = tn0 <= fminf(tf0, best) && tf0 >= 0.0f;
-            const bool h1 = tn1 <= fminf(tf1, best) && tf1 >= 0.0f;
+            float tn0, tn1;
+            const bool h0 = bvh_box(q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, q3.x, q3.y, o, inv, ainv, best, tn0);
+            const bool h1 = bvh_box(q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, q3.x, q3.y, o, inv, ainv, best, tn1);
             const uint32_t c0 = __float_as_uint(q3.z), c1 = __float_as_uint(q3.w);
             if (h0 && h1)
             {
@@ -645,7 +640,7 @@ __device__ __forceinline__ void sweep_bvh(const R1DeviceScene &S, const bool ali
         if (cur != R1_BVH_DONE)
         {
             // leaf: `cnt` PAIRS of spheres {cx_a cx_b cy_a cy_b} {cz_a cz_b rsq_a rsq_b}; an odd
-            // sphere's partner has radius_sq = -inf (discriminant -inf: never flagged)
+            // sphere's partner has radius_sq = -inf (discriminant -inf: never offers a hit)
             const uint32_t first = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
             for (uint32_t j = 0; j < cnt; ++j)
             {
@@ -656,23 +651,13 @@ __device__ __forceinline__ void sweep_bvh(const R1DeviceScene &S, const bool ali
                         wstat[3] += 1;
                 }
                 const float4 p0 = prims[2 * (size_t)(first + j)], p1 = prims[2 * (size_t)(first + j) + 1];
-                const f2 sx = {p0.x, p0.y}, sy = {p0.z, p0.w}, sz = {p1.x, p1.y}, rsq = {p1.z, p1.w};
-                // exact_offer's operations (rayweek1.cpp:192-202), two spheres per instruction
-                const f2 cox = sx - ox, coy = sy - oy, coz = sz - oz;
-                const f2 nb = fma2(coz, dz, fma2(coy, dy, cox * dx));
-                const f2 cc = fma2(coz, coz, fma2(coy, coy, cox * cox)) - rsq;
-                const f2 discr = nb * nb - cc;
-                uint32_t flags = (__float_as_uint(discr.x) >> 31 ? 0u : 1u) | (__float_as_uint(discr.y) >> 31 ? 0u : 2u);
-                while (flags)
+#pragma unroll
+                for (uint32_t c = 0; c < 2u; ++c)
                 {
-                    const uint32_t c = (flags & 1u) ? 0u : 1u;
-                    flags &= ~(1u << c);
-                    const float nbc = c ? nb.y : nb.x, dc = c ? discr.y : discr.x;
-                    // pass 2 of Hitable::hit for this sphere (rayweek1.cpp:294-313), see exact_offer
-                    const float root = ieee_sqrt(dc);
-                    const float t1 = nbc - root;
-                    const float t = (t1 > 0.001f) ? t1 : nbc + root;
-                    if (t > 0.001f && t < FLT_MAX && t <= best)
+                    f4 e;
+                    e.x = c ? p0.y : p0.x, e.y = c ? p0.w : p0.z, e.z = c ? p1.y : p1.x, e.w = c ? p1.w : p1.z;
+                    const float t = exact_offer(e, o, d); // the reference's pass 1 + pass 2 for this sphere
+                    if (t <= best && t < FLT_MAX)
                     {
                         const uint32_t id = ids[2 * (size_t)(first + j) + c];
                         if (t < best || id < best_id)
