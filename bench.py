@@ -358,7 +358,7 @@ def main():
                                   "frac": local_rays * 16.0 * n_pad * frames / elapsed / 1e12 / FP32_VECTOR_PEAK_TF,
                                   "note": ("reference-equivalent rate: 16 flop per ray-sphere test of the reference's sweep x N_pad "
                                            "spheres per ray (SURVEY.md §8d) / elapsed.  The box tree presents ~6 spheres per ray, so this is "
-                                           "not work the kernel does; its own load is 0.76 G VALU wave-instructions per frame, ~88 % "
+                                           "not work the kernel does; its own load is 0.89 G VALU wave-instructions per frame, ~88 % "
                                            "VALU-issue busy (profiles/r01/pmc_counters_tree_kernel.json, DESIGN.md §4.4)")
                                   if is_tree else
                                           ("16 flop per ray-sphere test of the reference's sweep (SURVEY.md §8d), i.e. counting the sphere "
