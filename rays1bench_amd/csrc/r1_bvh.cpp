@@ -119,7 +119,7 @@ struct Builder
 
     uint32_t make_leaf(uint32_t b, uint32_t e)
     {
-        // spheres are stored in PAIRS (the kernel tests two per packed instruction); the partner of
+        // spheres are stored in PAIRS (two spheres per pair of 16-byte loads); the partner of
         // an odd sphere has radius_sq = -inf, which makes its discriminant -inf: never flagged
         const uint32_t first = (uint32_t)(out->ids.size() / 2);
         const uint32_t pairs = (e - b + 1) / 2;
