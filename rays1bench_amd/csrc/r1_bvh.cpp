@@ -85,6 +85,7 @@ float round_up(double v)
 struct Builder
 {
     const float *cx, *cy, *cz, *rsq; // active order, the fp32 values the exact test reads
+    const double *rbound;             // radius the boxes must cover (r1_bound_radius)
     std::vector<Box> sphere;
     std::vector<uint32_t> order;
     R1Bvh *out;
@@ -264,7 +265,8 @@ struct Builder
 
 // Builds the tree over the `na` active spheres (fp32 arrays in active order).  Node 0 is always
 // an inner node (the root), even for 0 or 1 spheres.
-void r1_build_bvh(uint32_t na, const float *cx, const float *cy, const float *cz, const float *rsq, int leaf_max, R1Bvh &out)
+void r1_build_bvh(uint32_t na, const float *cx, const float *cy, const float *cz, const float *rsq, const double *rbound, int leaf_max,
+                  R1Bvh &out)
 {
     out.nodes.clear(), out.prims.clear(), out.ids.clear();
     out.max_depth = 0, out.n_leaves = 0;
@@ -273,7 +275,7 @@ void r1_build_bvh(uint32_t na, const float *cx, const float *cy, const float *cz
     if (leaf_max > 14)
         leaf_max = 14; // 7 pairs
     Builder B;
-    B.cx = cx, B.cy = cy, B.cz = cz, B.rsq = rsq;
+    B.cx = cx, B.cy = cy, B.cz = cz, B.rsq = rsq, B.rbound = rbound;
     B.out = &out;
     B.leaf_max = leaf_max;
     B.sphere.resize(na);
@@ -283,15 +285,18 @@ void r1_build_bvh(uint32_t na, const float *cx, const float *cy, const float *cz
         B.order[a] = a;
         Box &s = B.sphere[a];
         const double c[3] = {cx[a], cy[a], cz[a]};
-        const double r = rsq[a] > 0 ? std::sqrt((double)rsq[a]) : 0.0;
+        // extents cover rbound (>= the radius the exact test reads, r1_bound_radius); the error terms
+        // E1 / (2 r) follow the radius the test itself uses, sqrt(radius_sq) — the smaller, safer one
+        const double r = rbound[a];
+        const double r_test = rsq[a] > 0 ? std::min(r, std::sqrt((double)rsq[a])) : 0.0;
         // degenerate radii: bound sqrt(r^2 + E1) - r through r_floor (AM-GM), see the header
         const double r_floor = 1e-4 * (1.0 + std::fabs(c[0]) + std::fabs(c[1]) + std::fabs(c[2]));
-        const double r_eff = std::max(r, r_floor);
+        const double r_eff = std::max(r_test, r_floor);
         for (int k = 0; k < 3; ++k)
             s.lo[k] = c[k] - r, s.hi[k] = c[k] + r, s.clo[k] = s.chi[k] = c[k];
         s.kmax = 1.0 / (2.0 * r_eff);
         s.rmax = r;
-        s.floor_pad = r < r_floor ? 0.5 * r_floor : 0.0;
+        s.floor_pad = r_test < r_floor ? 0.5 * r_floor : 0.0;
     }
     // the root is node 0
     out.nodes.resize(16);
@@ -340,6 +345,44 @@ void r1_build_bvh(uint32_t na, const float *cx, const float *cy, const float *cz
         out.prims.assign(8, 0.0f), out.ids.assign(2, 0xFFFFFFFFu);
 }
 
+// The hittable ("active") spheres of a caller's scene, in scene order: inv_radius != 0
+// (rayweek1.cpp:291).  A sphere with a non-finite centre or radius_sq can never be hit by the
+// reference's arithmetic (NaN/inf discriminant or roots fail every compare, rayweek1.cpp:204,
+// :297-309) and is dropped like a placeholder, which also keeps such values out of the builders.
+// One helper for r1_set_scene and r1_bvh_describe, so both see the same spheres.
+extern "C" void r1_set_error(const char *fmt, ...);
+int r1_active_spheres(const r1_scene *s, std::vector<uint32_t> &active_to_scene)
+{
+    active_to_scene.clear();
+    for (uint32_t i = 0; i < s->count; ++i)
+    {
+        if (std::isnan(s->inv_radius[i]))
+        {
+            r1_set_error("scene: sphere %u has inv_radius NaN", i);
+            return R1_EINVAL;
+        }
+        if (s->inv_radius[i] == 0)
+            continue;
+        if (!std::isfinite(s->center_x[i]) || !std::isfinite(s->center_y[i]) || !std::isfinite(s->center_z[i]) ||
+            !std::isfinite(s->radius_sq[i]))
+            continue;
+        active_to_scene.push_back(i);
+    }
+    return R1_OK;
+}
+
+// Radius every conservative bound (group bounding spheres, tree boxes) must cover.  The hit test
+// reads radius_sq only (rayweek1.cpp:198); SphereSOA::add stores radius_sq = r*r and inv_radius =
+// 1/r of the same r (soa_sphere.cpp:70-85), but a C-ABI caller may hand over arrays that disagree
+// (or a negative inv_radius): taking the larger of the two keeps every bound conservative for
+// whatever the exact test can accept instead of silently dropping hits.
+double r1_bound_radius(float radius_sq, float inv_radius)
+{
+    const double from_sq = radius_sq > 0 ? std::sqrt((double)radius_sq) : 0.0;
+    const double from_inv = std::isfinite(inv_radius) && inv_radius != 0 ? 1.0 / std::fabs((double)inv_radius) : 0.0;
+    return std::max(from_sq, from_inv);
+}
+
 // Host-only view of the index (include/rays1.h): what r1_set_scene would build for this scene.
 extern "C" int r1_bvh_describe(const r1_scene *s, int32_t leaf_max, r1_bvh_info *info, float *nodes_out, size_t nodes_cap, uint32_t *ids_out,
                                size_t ids_cap)
@@ -347,18 +390,20 @@ extern "C" int r1_bvh_describe(const r1_scene *s, int32_t leaf_max, r1_bvh_info 
     if (!s || !info || !s->center_x || !s->center_y || !s->center_z || !s->radius_sq || !s->inv_radius)
         return R1_EINVAL;
     std::vector<float> x, y, z, r;
+    std::vector<double> rb;
     std::vector<uint32_t> scene_index;
-    for (uint32_t i = 0; i < s->count; ++i)
-        if (s->inv_radius[i] != 0)
-        {
-            x.push_back(s->center_x[i]), y.push_back(s->center_y[i]), z.push_back(s->center_z[i]), r.push_back(s->radius_sq[i]);
-            scene_index.push_back(i);
-        }
+    if (r1_active_spheres(s, scene_index) != R1_OK)
+        return R1_EINVAL;
+    for (uint32_t i : scene_index)
+    {
+        x.push_back(s->center_x[i]), y.push_back(s->center_y[i]), z.push_back(s->center_z[i]), r.push_back(s->radius_sq[i]);
+        rb.push_back(r1_bound_radius(s->radius_sq[i], s->inv_radius[i]));
+    }
     const uint32_t na = (uint32_t)x.size();
     if (na == 0)
-        x.push_back(0), y.push_back(0), z.push_back(0), r.push_back(0);
+        x.push_back(0), y.push_back(0), z.push_back(0), r.push_back(0), rb.push_back(0);
     R1Bvh b;
-    r1_build_bvh(na, x.data(), y.data(), z.data(), r.data(),
+    r1_build_bvh(na, x.data(), y.data(), z.data(), r.data(), rb.data(),
                  leaf_max > 0 ? leaf_max : (na > R1_MAX_ACTIVE_10BIT ? 2 * R1_BVH_LEAF : R1_BVH_LEAF), b);
     info->nodes = (int32_t)(b.nodes.size() / 16);
     info->leaves = (int32_t)b.n_leaves;

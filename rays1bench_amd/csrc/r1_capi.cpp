@@ -38,7 +38,10 @@ struct R1Bvh
     int max_depth = 0;
     uint32_t n_leaves = 0;
 };
-void r1_build_bvh(uint32_t na, const float *cx, const float *cy, const float *cz, const float *rsq, int leaf_max, R1Bvh &out);
+void r1_build_bvh(uint32_t na, const float *cx, const float *cy, const float *cz, const float *rsq, const double *rbound, int leaf_max,
+                  R1Bvh &out);
+int r1_active_spheres(const r1_scene *s, std::vector<uint32_t> &active_to_scene); // inv_radius != 0, finite (r1_bvh.cpp)
+double r1_bound_radius(float radius_sq, float inv_radius);
 
 // ---- errors ---------------------------------------------------------------------------------
 
@@ -80,6 +83,7 @@ struct r1_context
     int cus = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    hipEvent_t last0 = nullptr, last1 = nullptr, last2 = nullptr; // the events the last enqueued frame recorded (own set or ring slot)
     bool timing_valid = false;
     // optional per-frame event ring (r1_timing_begin/_end): 3 events per frame
     std::vector<hipEvent_t> ring;
@@ -273,8 +277,11 @@ static void bound_of(const std::vector<uint32_t> &m, const std::vector<double> &
     }
 }
 
+// lone[a]: sphere a must stay a group of its own (its radius_sq and inv_radius disagree, so the
+// R <= R1_GROUP_RATIO x r bound of the slack analysis cannot be relied on; a single-sphere group
+// needs no such bound: flagged by the reference means dist^2 <= r^2 + E1 <= R^2 + E1)
 static std::vector<R1Group> build_groups(uint32_t na, const std::vector<double> &x, const std::vector<double> &y,
-                                         const std::vector<double> &z, const std::vector<double> &r)
+                                         const std::vector<double> &z, const std::vector<double> &r, const std::vector<char> &lone)
 {
     // Grouping trades level-1 tests for extra member slots in the exact phase: it pays once the
     // sweep is long (large scene: 484 spheres, 1.5x), not for a few dozen spheres (medium scene:
@@ -300,7 +307,7 @@ static std::vector<R1Group> build_groups(uint32_t na, const std::vector<double> 
     const double r_med = rs[na / 2];
     std::vector<uint32_t> small;
     for (uint32_t a = 0; a < na; ++a)
-        if (gmax > 1 && r[a] <= 2.5 * r_med)
+        if (gmax > 1 && r[a] <= 2.5 * r_med && !lone[a])
             small.push_back(a);
         else
             close(std::vector<uint32_t>(1, a));
@@ -366,22 +373,14 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
 
     // active spheres: inv_radius != 0 (rayweek1.cpp:291); order preserved so that ties keep
     // the earlier index as in the reference's in-order resolve loop
-    c->active_to_scene.clear();
-    for (uint32_t i = 0; i < s->count; ++i)
-        if (s->inv_radius[i] != 0)
+    int rc_active = r1_active_spheres(s, c->active_to_scene);
+    if (rc_active != R1_OK)
+        return rc_active;
+    for (uint32_t i : c->active_to_scene)
+        if (s->mat_type[i] > R1_MAT_DIELECTRIC)
         {
-            // A sphere with a non-finite centre or radius_sq can never be hit by the reference's
-            // arithmetic (NaN/inf discriminant or roots fail every compare, rayweek1.cpp:204, :297-309):
-            // it is dropped here like a placeholder, which also keeps such values out of the tree builder.
-            if (!std::isfinite(s->center_x[i]) || !std::isfinite(s->center_y[i]) || !std::isfinite(s->center_z[i]) ||
-                !std::isfinite(s->radius_sq[i]))
-                continue;
-            if (s->mat_type[i] > R1_MAT_DIELECTRIC)
-            {
-                r1_set_error("r1_set_scene: sphere %u is hittable but has no material", i);
-                return R1_EINVAL;
-            }
-            c->active_to_scene.push_back(i);
+            r1_set_error("r1_set_scene: sphere %u is hittable but has no material", i);
+            return R1_EINVAL;
         }
     const uint32_t na = (uint32_t)c->active_to_scene.size();
     if (na > R1_MAX_ACTIVE)
@@ -391,13 +390,16 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
     }
     // level 1 of the sweep: groups of nearby spheres with a bounding sphere each
     std::vector<double> ax(na ? na : 1), ay(na ? na : 1), az(na ? na : 1), ar_(na ? na : 1);
+    std::vector<char> lone(na ? na : 1, 0);
     for (uint32_t a = 0; a < na; ++a)
     {
         const uint32_t i = c->active_to_scene[a];
         ax[a] = s->center_x[i], ay[a] = s->center_y[i], az[a] = s->center_z[i];
-        ar_[a] = 1.0 / (double)s->inv_radius[i]; // inv_radius != 0 means radius > 0 (soa_sphere.cpp:81)
+        ar_[a] = r1_bound_radius(s->radius_sq[i], s->inv_radius[i]); // what the exact test can accept, never less
+        const double r_test = s->radius_sq[i] > 0 ? sqrt((double)s->radius_sq[i]) : 0.0;
+        lone[a] = !(r_test >= ar_[a] * (1.0 - 1e-3)); // SphereSOA::add keeps them within 2 ulp (soa_sphere.cpp:70-85)
     }
-    std::vector<R1Group> groups = build_groups(na, ax, ay, az, ar_);
+    std::vector<R1Group> groups = build_groups(na, ax, ay, az, ar_, lone);
     // multi-member groups first: a flagged group with id >= n_multi is a single sphere and takes
     // one member slot of the exact phase instead of R1_GROUP_MAX
     std::stable_partition(groups.begin(), groups.end(), [](const R1Group &g) { return g.n > 1; });
@@ -470,7 +472,7 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
         // leaf size: 4 spheres (2 pairs) on the reference's scenes; 8 on big lattices (measured:
         // 100 004 spheres 3.43 ms against 3.67 ms per 1920x1080x4 frame)
         const int leaf_default = na > R1_MAX_ACTIVE_10BIT ? 2 * R1_BVH_LEAF : R1_BVH_LEAF;
-        r1_build_bvh(na, fx.data(), fy.data(), fz.data(), fr.data(), leaf_env > 0 ? leaf_env : leaf_default, bvh);
+        r1_build_bvh(na, fx.data(), fy.data(), fz.data(), fr.data(), ar_.data(), leaf_env > 0 ? leaf_env : leaf_default, bvh);
         if (bvh.max_depth > R1_BVH_STACK)
         {
             r1_set_error("r1_set_scene: spatial index deeper (%d) than the traversal stack (%d)", bvh.max_depth, R1_BVH_STACK);
@@ -754,7 +756,8 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     if (c->n_local_tiles)
         R1_HIP(r1_launch_resolve(&r, st));
     R1_HIP(hipEventRecord(e2, st));
-    c->timing_valid = !c->ring_on;
+    c->last0 = e0, c->last1 = e1, c->last2 = e2;
+    c->timing_valid = true;
 
     c->info.blocks = (int32_t)blocks;
     c->info.threads_per_block = R1_BLOCK;
@@ -829,7 +832,7 @@ static int render_host(r1_context *c, const r1_params *p, uint8_t *rgb_out, uint
     if (device_seconds_out)
     {
         float ms = 0;
-        R1_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev2));
+        R1_HIP(hipEventElapsedTime(&ms, c->last0, c->last2)); // the events THIS frame recorded (a ring slot while r1_timing_begin is on)
         *device_seconds_out = ms * 1e-3;
     }
     if (samples_out)
@@ -931,10 +934,10 @@ extern "C" int r1_last_timing(r1_context *c, double *trace_kernel_ms, double *to
         r1_set_error("r1_last_timing: nothing rendered yet");
         return R1_EINVAL;
     }
-    R1_HIP(hipEventSynchronize(c->ev2));
+    R1_HIP(hipEventSynchronize(c->last2));
     float a = 0, b = 0;
-    R1_HIP(hipEventElapsedTime(&a, c->ev0, c->ev1));
-    R1_HIP(hipEventElapsedTime(&b, c->ev0, c->ev2));
+    R1_HIP(hipEventElapsedTime(&a, c->last0, c->last1));
+    R1_HIP(hipEventElapsedTime(&b, c->last0, c->last2));
     if (trace_kernel_ms)
         *trace_kernel_ms = a;
     if (total_ms)

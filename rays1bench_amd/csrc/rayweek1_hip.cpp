@@ -139,6 +139,7 @@ RESULT benchmark(Scene *scene, Pix *pixels, bool write_tga, const char *scene_na
         // the reference has no error convention: report and return RESULT{0,0}
         fprintf(stderr, "%s: render failed (%d)\n", scene_name, rc);
         result.num_rays = 0;
+        g_device_seconds.push_back(0.0); // one entry per benchmark() call, failed ones included (log_json indexes by run)
         delete scene;
         return result;
     }
@@ -192,8 +193,10 @@ static void log_json(const char *version, const char *scene, const RESULT *resul
 {
     char filename[128];
     snprintf(filename, sizeof(filename), "out_%s.json", scene);
+    if (g_device_seconds.size() < (size_t)num_runs)
+        return;
     FILE *f = fopen(filename, "wt");
-    if (!f || g_device_seconds.size() < (size_t)num_runs)
+    if (!f)
         return;
     double el = 0, dev = 0;
     uint64_t rays = 0;

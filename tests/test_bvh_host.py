@@ -254,3 +254,74 @@ def test_discriminant_error_constant_behind_the_pad():
         v2 = (V * V).sum(1)
         worst = max(worst, float(((np.abs(discr - exact) - 2 * u * rsq) / (u * v2)).max()))
     assert worst < 23.0, worst
+
+
+# ---- round 2: the cases VERDICT r01 / ADVICE r01 name ---------------------------------------------
+
+
+@pytest.mark.parametrize("family", ["degenerate_radii", "camera_inside_big_sphere", "far_cluster"])
+def test_visit_rule_on_adversarial_families(family):
+    """The three families whose exactness rests on constants nobody had exercised: radii
+    1e-12..1e-6 (the r_floor branch of r1_bvh.cpp: radius_sq down to 1e-24), ray origins inside
+    an r = 50 sphere, and clusters 1e4..1e5 units from the world origin (fp32 spacing there is
+    1e-3..8e-3, comparable with the small radii)."""
+    rng = np.random.default_rng({"degenerate_radii": 71, "camera_inside_big_sphere": 72, "far_cluster": 73}[family])
+    n = 160
+    if family == "degenerate_radii":
+        c = rng.uniform(-3, 3, (n, 3))
+        rad = np.exp(rng.uniform(np.log(1e-12), np.log(1e-6), n))
+        origin = lambda: rng.uniform(-4, 4, 3)
+    elif family == "camera_inside_big_sphere":
+        c = rng.uniform(-20, 20, (n, 3))
+        rad = rng.uniform(0.1, 1.5, n)
+        c[0], rad[0] = (0.0, 0.0, 0.0), 50.0
+        origin = lambda: rng.uniform(-20, 20, 3)  # always inside sphere 0
+    else:
+        shift = np.array([3.0e4, -8.0e4, 1.2e4]) * rng.uniform(0.4, 1.2)
+        c = rng.uniform(-6, 6, (n, 3)) + shift
+        rad = np.exp(rng.uniform(np.log(0.02), np.log(1.0), n))
+        origin = lambda: rng.uniform(-9, 9, 3) + shift
+    cs, arrs, mt = _raw_scene(c, rad)
+    info, nodes, ids = binding.bvh_describe(cs)
+    assert sorted(ids[ids != EMPTY].tolist()) == list(range(n))
+    cx, cy, cz, rsq = arrs["center_x"], arrs["center_y"], arrs["center_z"], arrs["radius_sq"]
+    hits = 0
+    for q in range(150):
+        o = origin().astype(F)
+        i = int(rng.integers(0, n))
+        # aim at (or just past the rim of) a sphere so that grazing cases are frequent
+        target = np.array([cx[i], cy[i], cz[i]], np.float64) + rng.normal(0, 1, 3) * rad[i] * rng.choice([0.0, 0.7, 1.0, 1.05])
+        d = target - o.astype(np.float64)
+        d = (d / np.linalg.norm(d)).astype(F)
+        flagged = set(np.nonzero(ref_flagged(cx, cy, cz, rsq, o, d))[0].tolist())
+        shown = set(ids[traverse(nodes, o, d, rng.integers(0, 2, 3) * 2 - 1)].tolist()) - {EMPTY}
+        assert flagged <= shown, (family, q, sorted(flagged - shown)[:5])
+        hits += len(flagged)
+    assert hits > 0  # the family does produce reference candidates (for degenerate radii: rounding-noise hits)
+
+
+def test_describe_filters_like_set_scene_and_bounds_follow_the_larger_radius():
+    """r1_bvh_describe builds exactly what r1_set_scene builds — non-finite centres /
+    radius_sq are dropped (they can never be hit), NaN inv_radius is an error — and a caller whose
+    radius_sq and inv_radius disagree (or whose inv_radius is negative) still gets boxes that cover
+    the radius the exact test reads."""
+    import ctypes as C
+    c = np.array([[0, 0, 0], [np.nan, 0, 0], [3, 0, 0], [6, 0, 0], [9, 0, 0], [np.inf, 1, 1]], F)
+    rad = np.array([1.0, 1.0, 0.5, 0.5, 0.25, 1.0], F)
+    cs, arrs, mt = _raw_scene(c, rad)
+    arrs["inv_radius"][2] = F(1 / 0.05)   # inv_radius of a 10x smaller sphere: bounds must follow radius_sq
+    arrs["inv_radius"][3] = F(-2.0)       # negative inv_radius (the reference would flip the normal, still hit)
+    arrs["radius_sq"][4] = F(np.inf)      # can never be hit: dropped
+    info, nodes, ids = binding.bvh_describe(cs)
+    assert sorted(ids[ids != EMPTY].tolist()) == [0, 2, 3]
+    cc = c.astype(np.float64)
+    r_true = np.sqrt(arrs["radius_sq"].astype(np.float64))
+    for n_, ci, ref, m, e, w2, k in walk(nodes):
+        if ref & LEAF:
+            for s in leaf_slots(ref):
+                if ids[s] != EMPTY:
+                    i = ids[s]
+                    assert (cc[i] - r_true[i] >= m - e - 1e-12).all() and (cc[i] + r_true[i] <= m + e + 1e-12).all()
+    arrs["inv_radius"][0] = F(np.nan)
+    info2 = binding.BvhInfo()
+    assert binding.lib().r1_bvh_describe(C.byref(cs), 0, C.byref(info2), None, 0, None, 0) == binding.R1_EINVAL
