@@ -82,7 +82,9 @@ def test_samples_match_reference_fixture_1200x800x10(renderer, name):
     got = samples[idx]
     same_rays = rays_of(got) == g["rays"]
     same_rgb = (got[:, :3].view(np.uint32) == g["rgb"].reshape(-1, 3).view(np.uint32)).all(1)
-    assert same_rays.mean() >= 1 - 1e-4 and same_rgb.mean() >= 1 - 1e-4, (same_rays.mean(), same_rgb.mean())
+    # exact: these are fixed seeds and fixtures, and the one documented deviation (powf(x, 5), module
+    # docstring) flips none of their samples
+    assert same_rays.all() and same_rgb.all(), (int((~same_rays).sum()), int((~same_rgb).sum()))
     # whole-frame invariants
     assert int(rays_of(samples).sum()) == rays
     assert rays_of(samples).min() >= 1 and rays_of(samples).max() <= 51
