@@ -29,6 +29,16 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_VECTOR_PEAK_TF = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(scene, w, h, spp):
     """Times the reference's own step13 scheduler + render_tile (oracle/_ref, kind
     "reference") on the host cores; falls back to the oracle port.  Bounded to ~10-20 s."""
@@ -41,7 +51,9 @@ def cpu_baseline(scene, w, h, spp):
             return None
         return [json.loads(l) for l in out.stdout.decode().strip().splitlines()]
 
-    for prefer_native in (True, False):
+    # the x86-64-v3 (AVX2 + FMA) build first: `-march=native` of the build container is another
+    # machine's native on the GPU box
+    for prefer_native in (False, True):
         binary = r1o.ref_binary(prefer_native)
         if not binary:
             continue
@@ -59,9 +71,10 @@ def cpu_baseline(scene, w, h, spp):
         rec = rec[1:]  # first run pays page faults / thread start
         rays = sum(r["rays"] for r in rec)
         secs = sum(r["seconds"] for r in rec)
-        return {"value": rays / secs / 1e6, "unit": "mrays/s", "cores": rec[0]["threads"], "kind": "reference",
+        return {"value": rays / secs / 1e6, "unit": "mrays/s", "cores": rec[0]["threads"], "kind": "reference", "cpu_model": cpu_model(),
                 "sample": f"{scene} {w}x{h}x{spp}: {len(rec)} frames through the reference's TileRenderScheduler/render_tile "
-                          f"({os.path.basename(binary)}, flags of reference bench.py:175), {secs:.1f} s"}
+                          f"({os.path.basename(binary)}: flags of reference bench.py:175 with "
+                          f"{'-march=x86-64-v3' if 'avx2' in os.path.basename(binary) else '-march=native of the build container'}), {secs:.1f} s"}
     # port: the oracle's restatement of the threaded path
     import rays1bench_amd as r1
     sc = r1.Scene(SCENE_KIND[scene], w, h)
@@ -71,7 +84,7 @@ def cpu_baseline(scene, w, h, spp):
         rays += r1o.render_threads(sa, w, h, spp, 0)[1]
         n += 1
     secs = time.perf_counter() - t0
-    return {"value": rays / secs / 1e6, "unit": "mrays/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": rays / secs / 1e6, "unit": "mrays/s", "cores": os.cpu_count(), "kind": "port", "cpu_model": cpu_model(),
             "sample": f"{scene} {w}x{h}x{spp}: {n} frames through oracle/r1_oracle.c r1o_render_threads, {secs:.1f} s"}
 
 
@@ -117,9 +130,46 @@ def cpu_baseline_grid(sc, w, h):
         t0 = time.perf_counter()
         rays = r1o.render_threads(sa, sw, sh, sspp, 0)[1]
         secs = time.perf_counter() - t0
-    return {"value": rays / secs / 1e6, "unit": "mrays/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": rays / secs / 1e6, "unit": "mrays/s", "cores": os.cpu_count(), "kind": "port", "cpu_model": cpu_model(),
             "sample": f"same scene and camera, {sw}x{sh}x{sspp} frame through oracle/r1_oracle.c r1o_render_threads "
                       f"(exhaustive AVX2 sweep, the reference's algorithm), {secs:.1f} s"}
+
+
+# flop per unit of the hit tests, counted from r1_kernels.hip (add / mul / compare / min / max = 1, fma = 2):
+#   bvh_box      3 sub, |m-o|^2 (mul + 2 fma), pad fma, 3 mul, 3 add + 3 mul, 3 sub + 2 max, 3 add + 2 min, min + 2 cmp  = 32
+#   exact_offer  pass 1 of Hitable::hit for one sphere = SURVEY.md §8d's 16 flop (3 sub, mul + 2 fma, mul + 2 fma, sub, mul + sub)
+#   group test   7 fma + 1 sub of the prefilter (sweep_prefilter)                                                       = 15
+FLOP_BOX, FLOP_SPHERE, FLOP_GROUP = 32.0, 16.0, 15.0
+
+
+def measure_work(rend, p, info, binding):
+    """Counts what one launch of the timed kernel executes: a synchronous frame through the
+    diagnostic build of the same kernel (same samples; tools/bvh_stats.py, tools/kernel_stats.py)."""
+    import ctypes as C
+    import numpy as np
+    stats_variant = binding.VARIANT_BVH_STATS if info["kernel"] == 4 else binding.VARIANT_STATS
+    q = binding.Params.from_buffer_copy(p)
+    q.variant = stats_variant
+    host = np.zeros((p.height, p.width, 3), np.uint8)
+    rays, _ = rend.render_into(q, host)
+    st = rend.last_stats()
+    it = max(st["wave_iterations"], 1)
+    if info["kernel"] == 4:
+        visits, pairs = st["candidates"], st["cycles_pass1"]
+        return {"source": "R1_VARIANT_BVH_STATS frame (same samples as the timed kernel)", "rays_per_launch": rays,
+                "node_visits_per_ray": visits / rays, "sphere_pair_tests_per_ray": pairs / rays,
+                "flop_per_node_visit": 2 * FLOP_BOX, "flop_per_sphere_pair_test": 2 * FLOP_SPHERE,
+                "flop_per_launch": visits * 2 * FLOP_BOX + pairs * 2 * FLOP_SPHERE,
+                "lane_utilisation": {"at_hit_test": st["alive_lanes"] / (64.0 * it),
+                                     "node_loop": visits / (64.0 * max(st["candidate_loop_trips"], 1)),
+                                     "leaf_loop": pairs / (64.0 * max(st["overflow_lanes"], 1))}}
+    groups = info["groups"]
+    slots = st["candidate_loop_trips"] * 64  # member slots the cooperative exact phase walked
+    return {"source": "R1_VARIANT_STATS frame (same samples as the timed kernel)", "rays_per_launch": rays,
+            "group_tests_per_ray": float(groups), "exact_slots_per_ray": slots / rays,
+            "flop_per_group_test": FLOP_GROUP, "flop_per_exact_slot": FLOP_SPHERE,
+            "flop_per_launch": rays * groups * FLOP_GROUP + slots * FLOP_SPHERE,
+            "lane_utilisation": {"at_hit_test": st["alive_lanes"] / (64.0 * it)}}
 
 
 def main():
@@ -282,8 +332,16 @@ def main():
             step()
         fence()
         sweep_elapsed = time.perf_counter() - t1
-        sweep_line = {"value": rays_per_step * sweep_steps / sweep_elapsed / 1e6, "unit": "mrays/s", "steps": sweep_steps,
+        sweep_rate = rays_per_step * sweep_steps / sweep_elapsed
+        sweep_line = {"value": sweep_rate / 1e6, "unit": "mrays/s", "steps": sweep_steps,
                       "ms_per_step": sweep_elapsed / sweep_steps * 1e3,
+                      "reference_equivalent": {
+                          "bytes_per_ray": 16.0 * info["spheres_padded"], "flop_per_ray": 16.0 * info["spheres_padded"],
+                          "tb_per_s": sweep_rate * 16.0 * info["spheres_padded"] / 1e12,
+                          "tflop_per_s": sweep_rate * 16.0 * info["spheres_padded"] / 1e12,
+                          "note": "SURVEY.md §8d's model of the REFERENCE's sweep (16 B and 16 flop per ray-sphere test x N_pad spheres "
+                                  "per ray) at this kernel's ray rate.  Reference-equivalent, not executed, work: the kernel tests "
+                                  "groups of <= 4 spheres from SGPRs, so these figures may exceed the hardware peaks (8 TB/s, 157.3 TFLOP/s)"},
                       "kernel": "grouped exhaustive sweep (R1_VARIANT_PREFILTER): every ray tested against every sphere group, "
                                 "as the reference's Hitable::hit does; same pixels"}
         p = p_main
@@ -304,24 +362,62 @@ def main():
         ref_rays, _ = rend.render_into(r1.make_params(w, h, spp, args.seed, variant=args.variant), ref)
         check = bool(got.tobytes() == ref.tobytes() and got_rays == ref_rays)
 
+    # ---- what the timed kernel executes (measured, outside the timed region): one synchronous frame
+    # through the diagnostic build of the same kernel (R1_VARIANT_*_STATS: same samples, plus counters)
+    work = None
+    if rank == 0 and (info["kernel"] == 4 or (info["kernel"] == 2 and info["spheres_active"] <= 1023)):
+        try:
+            work = measure_work(rend, p, info, binding)
+        except Exception as e:  # diagnostics never fail the bench
+            work = {"error": str(e)}
+
     if rank == 0:
         n_pad = info["spheres_padded"]
         is_tree = info["kernel"] in (4, 5, 6)
         kernel_name = {1: "reference-form exhaustive sweep", 2: "grouped exhaustive sweep" + (" (LDS-tiled)" if info["spheres_active"] > 1023 else ""),
                        3: "grouped exhaustive sweep + counters", 4: "box tree (R1_VARIANT_BVH)", 5: "box tree + counters",
                        6: "wavefront: generate / intersect / shade kernels, box tree (comparison build)"}[info["kernel"]]
-        kernel_s = trace_ms_sum / max(frames, 1) * 1e-3
-        alg_bytes = local_rays * 16.0 * n_pad  # 16 B per ray-sphere test x N_pad spheres per ray
-        achieved = alg_bytes / kernel_s / 1e9
-        traffic = None
+        kernel_s = trace_ms_sum / max(frames, 1) * 1e-3  # average launch duration, HIP events on the stream of each launch
+        overlap = trace_ms_sum * 1e-3 / elapsed           # launches of different frames overlap (frames in flight)
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and info["kernel"] != 6:
             try:
                 tj = json.load(open(tpath))
-                if tj.get("workload") == f"{args.scene} {w}x{h}x{spp}" and n == 1:
+                if tj.get("workload") == f"{args.scene} {w}x{h}x{spp}" and n == 1 and tj.get("kernel_variant") == info["kernel"]:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = f"profiles/pmc_traffic.json: {tj.get('source', 'rocprofv3 --pmc passes')} (not measured by this run)"
             except Exception:
                 traffic = None
+        flop = work.get("flop_per_launch") if work else None
+        roofline = {
+            # No dense contraction on this path (no MFMA) and the tables are cache resident, so neither of
+            # the contract's two roofs binds: the roof is fp32 VECTOR issue.  `achieved` counts the flop the
+            # launch EXECUTES in its hit tests (measured counts x flop per unit, below) — never the
+            # reference-equivalent 16 B x N_pad model (that figure lives in `exhaustive_sweep`).
+            "bound": "valu", "peak": FP32_VECTOR_PEAK_TF, "unit": "TFLOP/s",
+            "achieved": (flop / kernel_s / 1e12) if flop else None,
+            "frac": (flop / kernel_s / 1e12 / FP32_VECTOR_PEAK_TF) if flop else None,
+            "traffic": traffic, "traffic_source": traffic_source,
+            "kernel": "r1_trace_kernel" if info["kernel"] != 6 else "r1_wf_generate + 51 x (r1_wf_intersect, r1_wf_shade)",
+            "kernel_ms": kernel_s * 1e3,
+            "flop_per_launch": flop,
+            "work": work,
+            # with several frames in flight the launches overlap: `achieved` is per launch as the contract
+            # defines it (flop per launch / average launch duration); x launch_overlap = what the chip sustains
+            "launch_overlap": overlap,
+            "achieved_aggregate": (flop * frames / elapsed / 1e12) if flop else None,
+            "frac_aggregate": (flop * frames / elapsed / 1e12 / FP32_VECTOR_PEAK_TF) if flop else None,
+            "hbm": {"peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "achieved": (traffic / kernel_s / 1e9) if traffic else None,
+                    "achieved_aggregate": (traffic * frames / elapsed / 1e9) if traffic else None,
+                    "frac_aggregate": (traffic * frames / elapsed / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                    "note": "measured HBM bytes per launch (PMC) / time: the sample records and the image; sphere and node tables stay in L1/L2"},
+            "note": "executed hit-test flop / launch duration / fp32 vector peak (157.3 TFLOP/s).  Low by construction: the count "
+                    "leaves out shading, RNG, queue and control instructions, idle lanes of divergent traversals "
+                    "(work.lane_utilisation) and the 4-cycle issue of VOP3 instructions; VALU issue-busy cycles are in "
+                    "profiles/ (DESIGN.md §7).",
+        }
         out = {
             "metric": f"mrays/s on '{args.scene}' scene {w}x{h}x{spp}spp",
             "value": value, "unit": "mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
@@ -331,56 +427,36 @@ def main():
                                    f"max 50 bounces, seed {args.seed}",
                        "rays_per_step": rays_per_step, "tiles": "32x32, tile t -> rank t % N",
                        "parallelism": f"tile-split x{n}" + (" + one RCCL all-gather per frame (pixels + ray counts)" if n > 1 else ""),
+                       "value_mode": f"{len(slots)} frames in flight (one stream + context each), scene and image resident in HBM",
                        "workgroups": info["blocks"], "threads_per_workgroup": info["threads_per_block"],
                        "frames_in_flight": len(slots), "host_submit_ms_per_step": submit / args.steps * 1e3,
                        "kernel": kernel_name,
                        **({"bvh": {"nodes": info["bvh_nodes"], "leaves": info["bvh_leaves"], "depth": info["bvh_depth"]}} if is_tree else {})},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic if info["kernel"] != 6 else None,
-                         "kernel": "r1_trace_kernel" if info["kernel"] != 6 else "r1_wf_generate + 51 x (r1_wf_intersect, r1_wf_shade)",
-                         "kernel_ms": kernel_s * 1e3,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         # with several frames in flight the launches overlap (launch_overlap = sum of launch
-                         # durations / elapsed): `achieved` is per launch as the contract defines it,
-                         # `achieved_aggregate` = achieved x overlap is what the chip sustains.
-                         "launch_overlap": trace_ms_sum * 1e-3 / elapsed,
-                         "achieved_aggregate": alg_bytes * frames / elapsed / 1e9,
-                         "frac_aggregate": alg_bytes * frames / elapsed / 1e9 / HBM_PEAK_GBS,
-                         "note": ("algorithmic bytes = rays x 16 B x N_pad (the streaming model of the reference's sweep); this "
-                                  "launch ran the box tree, which presents ~5 spheres per ray to the reference's test instead of "
-                                  "N_pad, so the fraction only says how far the result is from what streaming the table could "
-                                  "deliver; the kernel itself is bound by VALU issue and divergent node fetches (DESIGN.md §4.4)")
-                         if is_tree else
-                                 ("algorithmic bytes = rays x 16 B x N_pad (the streaming model of the reference's sweep); the "
-                                  "table is SGPR/cache resident and spheres are tested in groups of <= 4 behind a conservative "
-                                  "bound, so this fraction can exceed 1 and the binding roof is fp32 VALU issue"),
-                         "valu": {"achieved_tflops": local_rays * 16.0 * n_pad * frames / elapsed / 1e12, "peak_tflops": FP32_VECTOR_PEAK_TF,
-                                  "frac": local_rays * 16.0 * n_pad * frames / elapsed / 1e12 / FP32_VECTOR_PEAK_TF,
-                                  "note": ("reference-equivalent rate: 16 flop per ray-sphere test of the reference's sweep x N_pad "
-                                           "spheres per ray (SURVEY.md §8d) / elapsed.  The box tree presents ~6 spheres per ray, so this is "
-                                           "not work the kernel does; its own load is 0.89 G VALU wave-instructions per frame, ~88 % "
-                                           "VALU-issue busy (profiles/r01/pmc_counters_tree_kernel.json, DESIGN.md §4.4)")
-                                  if is_tree else
-                                          ("16 flop per ray-sphere test of the reference's sweep (SURVEY.md §8d), i.e. counting the sphere "
-                                           "tests the group tests stand for; aggregate over the timed region (all launches / "
-                                           "elapsed); one isolated launch (--inflight 1): DESIGN.md §7")}},
+            "roofline": roofline,
         }
         if sweep_line is not None:
             out["exhaustive_sweep"] = sweep_line
         if check is not None:
             out["check"] = check
         if n == 1:
-            # PCIe-inclusive: the host-returning entry point (pixels + count copied back every frame)
+            # The survey's timer span (rayweek1.cpp:848 -> :891): dispatch -> pixels + ray count on the HOST,
+            # one synchronous frame at a time through r1_render() — what the drop-in benchmark() prints.
             import numpy as np
             host = np.zeros((h, w, 3), np.uint8)
             ph = r1.make_params(w, h, spp, args.seed, variant=args.variant)
             rend.render_into(ph, host)
+            reps = max(5, min(args.steps, 50))
             t1 = time.perf_counter()
-            reps = max(3, min(args.steps, 20))
-            tot = 0
+            tot, dev_s = 0, 0.0
             for _ in range(reps):
-                tot += rend.render_into(ph, host)[0]
-            out["pcie_inclusive_mrays_per_s"] = tot / (time.perf_counter() - t1) / 1e6
+                r_, s_ = rend.render_into(ph, host)
+                tot, dev_s = tot + r_, dev_s + s_
+            d2h = time.perf_counter() - t1
+            out["value_dispatch_to_host"] = {
+                "value": tot / d2h / 1e6, "unit": "mrays/s", "ms_per_step": d2h / reps * 1e3, "steps": reps,
+                "device_ms_per_step": dev_s / reps * 1e3,
+                "span": "r1_render(): launch -> pixels + ray count on the host (the reference's Timer span, rayweek1.cpp:848 -> :891), "
+                        "one frame at a time, PCIe copy included"}
             if not args.no_cpu_baseline:
                 try:
                     out["cpu_baseline"] = cpu_baseline_grid(slots[0].scene, w, h) if args.scene == "grid" else cpu_baseline(args.scene, w, h, spp)
