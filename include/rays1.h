@@ -212,6 +212,10 @@ int r1_timing_end(r1_context *ctx, double *trace_ms_sum, double *total_ms_sum, i
  * candidate re-test / shade, [8] wave cycles, [9] candidates. */
 int r1_last_stats(r1_context *ctx, uint64_t *out16);
 
+/* Per-wave log of the last R1_VARIANT_*_STATS render: 4 uint64 per wave {start, sample queue found
+ * empty, end (100 MHz device clock), outer iterations}.  out == NULL only returns the wave count.  Diagnostic. */
+int r1_last_wave_log(r1_context *ctx, uint64_t *out, size_t cap_waves, uint32_t *waves);
+
 /* Launch geometry and occupancy facts of the last render (for reports). */
 typedef struct r1_launch_info
 {

@@ -95,6 +95,7 @@ SYMBOLS = [
     ("r1_timing_end", C.c_int, [_ctx, _dblp, _dblp, _i32p]),
     ("r1_last_stats", C.c_int, [_ctx, _u64p]),
     ("r1_last_launch_info", C.c_int, [_ctx, C.POINTER(LaunchInfo)]),
+    ("r1_last_wave_log", C.c_int, [_ctx, _u64p, C.c_size_t, C.POINTER(C.c_uint32)]),
     ("r1_host_scene_create", C.c_int, [C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     ("r1_host_scene_destroy", None, [C.c_void_p]),
     ("r1_host_scene_spheres", C.POINTER(CScene), [C.c_void_p]),
@@ -260,6 +261,14 @@ class Renderer:
         d["shortest_wave_cycles"] = m - int(out[11])
         d["span_cycles"] = int(out[12]) - (m - int(out[13]))
         return d
+
+    def wave_log(self):
+        n = C.c_uint32()
+        _check(lib().r1_last_wave_log(self._c, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 4), np.uint64)
+        if n.value:
+            _check(lib().r1_last_wave_log(self._c, out.ctypes.data_as(_u64p), n.value, C.byref(n)))
+        return out
 
     def launch_info(self):
         li = LaunchInfo()

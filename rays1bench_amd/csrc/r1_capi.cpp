@@ -94,6 +94,11 @@ struct r1_context
     DevBuf sweep, exact, shade, mat, members;
     DevBuf bvh_nodes, bvh_prims, bvh_ids; // R1_VARIANT_BVH (r1_bvh.cpp)
     DevBuf wf_paths, wf_hits, wf_queue, wf_counts; // R1_VARIANT_WAVEFRONT workspace
+    DevBuf tile_order;                             // latency mode: queue position -> local tile (costly tiles first)
+    bool tile_order_valid = false;
+    DevBuf wave_log;                               // STATS builds: per-wave {start, queue empty, end, iterations}
+    unsigned long long wave_log_ptr = 0;
+    uint32_t wave_log_waves = 0;
     uint32_t n_bvh_nodes = 0, n_bvh_leaves = 0;
     int bvh_depth = 0;
     uint32_t n_active = 0, n_sweep = 0, n_padded_scene = 0, n_groups = 0, n_multi = 0;
@@ -206,6 +211,7 @@ extern "C" void r1_destroy(r1_context *c)
     release(c->bvh_nodes), release(c->bvh_prims), release(c->bvh_ids);
     release(c->wf_paths), release(c->wf_hits), release(c->wf_queue), release(c->wf_counts);
     release(c->gstack), release(c->counters), release(c->samples), release(c->image);
+    release(c->wave_log), release(c->tile_order);
     for (hipEvent_t e : c->ring)
         (void)hipEventDestroy(e);
     if (c->ev0)
@@ -516,6 +522,7 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
     memcpy(c->cam.v, cam->v, 12);
     c->cam.lens_radius = cam->lens_radius;
     c->have_scene = true;
+    c->tile_order_valid = false;
     return R1_OK;
 }
 
@@ -559,6 +566,7 @@ static int prepare_tiles(r1_context *c, const r1_params *p)
         r1_set_error("frame %dx%dx%d with %dx%d tiles exceeds 2^31 sample slots per device", p->width, p->height, p->spp, p->tile_w, p->tile_h);
         return R1_ELIMIT;
     }
+    c->tile_order_valid = false;
     c->n_local_tiles = local;
     c->full = (uint32_t)full;
     c->total_samples = (uint32_t)(full * local);
@@ -598,7 +606,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     R1_HIP(hipSetDevice(c->device));
     if ((rc = prepare_tiles(c, p)))
         return rc;
-    if ((rc = ensure(c->counters, 512)))
+    if ((rc = ensure(c->counters, R1_COUNTER_BYTES)))
         return rc;
     if ((rc = ensure(c->samples, (size_t)(c->total_samples ? c->total_samples : 1) * 16)))
         return rc;
@@ -631,7 +639,12 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     a.div_tw = make_div((uint32_t)p->tile_w);
     a.div_tx = make_div((uint32_t)a.tiles_x);
     a.total_samples = c->total_samples;
-    a.queue = (uint32_t *)c->counters.p;
+    a.queue = (uint32_t *)((char *)c->counters.p + 1024);
+    a.nq = 1;
+    {
+        static const int coop_env = getenv("R1_COOP_LANES") ? atoi(getenv("R1_COOP_LANES")) : -1;
+        a.coop_lanes = coop_env >= 0 ? (uint32_t)coop_env : R1_COOP_LANES;
+    }
     a.samples = (float4 *)c->samples.p;
     a.num_rays = (unsigned long long *)d_rays;
     a.stats = (variant == 3 || variant == 5) ? (unsigned long long *)((char *)c->counters.p + 128) : nullptr;
@@ -690,6 +703,50 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
         if (a.chunk_min > a.chunk_max)
             a.chunk_min = a.chunk_max;
     }
+    // Latency mode: every wave of the full grid takes one wave-full of samples per atomic (what a wave
+    // still holds when the queue runs dry is the frame's tail: with 256-sample chunks the waves found
+    // the queue empty over a span of 0.7 ms), which one counter cannot serve: sub-queues.
+    if (!throughput_mode)
+    {
+        static const int nq_env = getenv("R1_NQ") ? atoi(getenv("R1_NQ")) : 0, ch_env = getenv("R1_CHUNK") ? atoi(getenv("R1_CHUNK")) : 0;
+        long long nq = nq_env > 0 ? nq_env : R1_SUBQUEUES;
+        // a wave only ever pulls from its home sub-queue (r1_kernels.hip: home = (4 (block / 8) + wave) % nq), so every
+        // sub-queue needs home waves: the full groups of 8 workgroups must cover all nq residues
+        if (nq > 4 * (blocks / 8))
+            nq = 4 * (blocks / 8);
+        if (nq > (R1_COUNTER_BYTES - 1024) / 128)
+            nq = (R1_COUNTER_BYTES - 1024) / 128;
+        if (nq > 1)
+        {
+            a.nq = (uint32_t)nq;
+            a.chunk_max = a.chunk_min = ch_env > 0 ? (uint32_t)ch_env : 64u;
+        }
+    }
+    if (!throughput_mode && c->n_local_tiles > 1)
+    {
+        static const char *hack = getenv("R1_TILE_ORDER_HACK"); // experiment: "lo,hi" = tile rows [lo, hi) enter the queue first
+        if (hack)
+        {
+            if (!c->tile_order_valid)
+            {
+                int lo = 0, hi = 0;
+                sscanf(hack, "%d,%d", &lo, &hi);
+                std::vector<uint32_t> order, rest;
+                for (uint32_t j = 0; j < c->n_local_tiles; ++j)
+                {
+                    const int row = (int)((uint32_t)p->shard + j * (uint32_t)p->num_shards) / a.tiles_x;
+                    (row >= lo && row < hi ? order : rest).push_back(j);
+                }
+                order.insert(order.end(), rest.begin(), rest.end());
+                if ((rc = ensure(c->tile_order, order.size() * 4)))
+                    return rc;
+                R1_HIP(hipStreamSynchronize(st));
+                R1_HIP(hipMemcpy(c->tile_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice));
+                c->tile_order_valid = true;
+            }
+            a.tile_order = (const uint32_t *)c->tile_order.p;
+        }
+    }
     hipEvent_t e0 = c->ev0, e1 = c->ev1, e2 = c->ev2;
     if (c->ring_on && c->ring_frames > 0)
     {
@@ -704,9 +761,16 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
             return rc;
         a.gstack = (uint32_t *)c->gstack.p;
     }
-    R1_HIP(hipMemsetAsync(c->counters.p, 0, 64, st));
+    R1_HIP(hipMemsetAsync(c->counters.p, 0, R1_COUNTER_BYTES, st));
     if (variant == 3 || variant == 5)
-        R1_HIP(hipMemsetAsync((char *)c->counters.p + 128, 0, 128, st));
+    {
+        c->wave_log_waves = (uint32_t)blocks * (R1_BLOCK / 64);
+        if ((rc = ensure(c->wave_log, (size_t)c->wave_log_waves * 32)))
+            return rc;
+        R1_HIP(hipMemsetAsync(c->wave_log.p, 0, (size_t)c->wave_log_waves * 32, st));
+        c->wave_log_ptr = (unsigned long long)c->wave_log.p;
+        R1_HIP(hipMemcpyAsync((char *)c->counters.p + 128 + 15 * 8, &c->wave_log_ptr, 8, hipMemcpyHostToDevice, st));
+    }
     R1_HIP(hipMemsetAsync(d_rays, 0, 8, st));
     R1_HIP(hipEventRecord(e0, st));
     if (c->total_samples && variant != 6)
@@ -796,7 +860,7 @@ static int render_host(r1_context *c, const r1_params *p, uint8_t *rgb_out, uint
     const size_t out_bytes = sharded ? r1_shard_block_bytes(p) : img_bytes;
     if ((rc = ensure(c->image, out_bytes + 64)))
         return rc;
-    if ((rc = ensure(c->counters, 512)))
+    if ((rc = ensure(c->counters, R1_COUNTER_BYTES)))
         return rc;
     void *d_rays = (char *)c->counters.p + 32;
     if ((rc = enqueue_frame(c, p, c->image.p, sharded ? 1 : 0, d_rays, c->stream, false)))
@@ -952,6 +1016,21 @@ extern "C" int r1_last_stats(r1_context *c, uint64_t *out16)
     R1_HIP(hipSetDevice(c->device));
     R1_HIP(hipStreamSynchronize(c->stream));
     R1_HIP(hipMemcpy(out16, (char *)c->counters.p + 128, 128, hipMemcpyDeviceToHost));
+    return R1_OK;
+}
+
+extern "C" int r1_last_wave_log(r1_context *c, uint64_t *out, size_t cap_waves, uint32_t *waves)
+{
+    if (!c || !waves)
+        return R1_EINVAL;
+    *waves = c->wave_log_waves;
+    if (!out)
+        return R1_OK;
+    if (cap_waves < c->wave_log_waves || !c->wave_log.p)
+        return R1_EINVAL;
+    R1_HIP(hipSetDevice(c->device));
+    R1_HIP(hipStreamSynchronize(c->stream));
+    R1_HIP(hipMemcpy(out, c->wave_log.p, (size_t)c->wave_log_waves * 32, hipMemcpyDeviceToHost));
     return R1_OK;
 }
 

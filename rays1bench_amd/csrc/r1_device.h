@@ -29,6 +29,9 @@
 #define R1_BVH_LEAF 4          // spheres per leaf (<= 14; stored as pairs)
 #define R1_TREE_SKIP_MIN 9     // DEFAULT kernel: exhaustive sweep for scenes of [R1_TREE_SKIP_MIN, R1_TREE_SKIP_MAX) hittable
 #define R1_TREE_SKIP_MAX 128   // spheres, box tree otherwise
+#define R1_SUBQUEUES 16        // latency mode: sub-queues of the sample queue (R1TraceArgs::nq)
+#define R1_COUNTER_BYTES 4096  // per-context counter block: queue heads, ray count, drain counts, stats, sub-queues at +1024
+#define R1_COOP_LANES 4        // R1TraceArgs::coop_lanes
 
 // Division of n < 2^31 by a launch constant: pow2 ? n >> shift : mulhi(n, mul) >> shift, with
 // mul = ceil(2^(32+shift) / d), shift = floor(log2 d) (exact for every n < 2^31; r1_capi.cpp).
@@ -89,12 +92,23 @@ struct R1TraceArgs
     R1FastDiv div_full, div_spp, div_tw, div_tx; // by full, spp, tile_w, tiles_x
     uint32_t total_samples;      // n_local_tiles * full (queue length)
     uint32_t chunk_min, chunk_max; // samples a wave takes from the queue per atomic (guided: remaining / (2 waves), clamped)
-    uint32_t *queue;             // global sample counter (zeroed before the launch)
+    const uint32_t *tile_order;  // null: queue position j is local tile j.  Else local tile = tile_order[j]: the order tiles ENTER the
+                                 // queue (costly tiles first, so that long bounce chains start early; r1_capi.cpp).  Storage and
+                                 // seeding follow the tile itself, so the image does not depend on the order.
+    uint32_t *queue;             // global sample counter(s) (zeroed before the launch); sub-queue q at queue + 32 q (its own 128-byte line)
+    uint32_t nq;                 // 1: one guided queue (chunk_min..chunk_max).  > 1 (latency mode): nq sub-queues of fixed chunks of
+                                 // chunk_max slots, chunk c belongs to sub-queue c % nq and a wave only pulls from sub-queue wave % nq:
+                                 // a returning atomic on ONE line sustains 88 M/s on this chip (tools/ubench_atomic.hip), too few for
+                                 // 6144 waves taking a wave-full at a time
     float4 *samples;             // [total_samples] {r, g, b, bit_cast<float>(rays)}
     unsigned long long *num_rays; // accumulated color() invocations
     uint32_t *gstack;             // big scenes: attenuation stack [R1_STACK_ENTRIES][grid threads], else null
     unsigned long long *stats;    // diagnostic counters (R1_VARIANT_STATS builds only), else null
     int32_t bvh_depth;            // tree kernels: traversal stack entries per thread (dynamic LDS = depth * R1_BLOCK * 4)
+    uint32_t coop_lanes;          // small scenes: once the queue is empty, a wave with <= coop_lanes live paths tests each of them
+                                  // against ALL spheres, 64 at a time across the wave (cooperative_sweep), instead of walking the tree
+                                  // with 60 lanes masked off: the frame's tail is a few 51-bounce chains, and this shortens a step
+                                  // of such a chain from ~16 k cycles of dependent node fetches to ~4 k
 };
 
 // Wavefront variant (R1_VARIANT_WAVEFRONT): the same path tracer split into

@@ -675,6 +675,52 @@ __device__ __forceinline__ void sweep_bvh(const R1DeviceScene &S, const bool ali
     }
 }
 
+// ---- the tail of a frame: a few live paths per wave ------------------------------------------------
+// Every live ray of the wave in turn against ALL active spheres, lane l testing spheres l, l + 64, ...
+// with the reference's per-sphere arithmetic (exact_offer), then the minimum offer, ties to the lowest
+// index (the reference's in-order rule, see exact_offer).  Same result as the other sweeps; meant for
+// waves that have only a handful of paths left (R1TraceArgs::coop_lanes): one such step costs the wave
+// ~n_active / 64 sphere tests per ray and a single round of coalesced loads instead of a walk down the
+// tree made of dependent fetches.  Called by all 64 lanes.
+__device__ __forceinline__ void cooperative_sweep(const R1DeviceScene &S, unsigned long long live, const V3 o, const V3 d, float &t_max,
+                                                  int &hit_index, const int lane)
+{
+    const f4 *__restrict__ tab = (const f4 *)S.exact;
+    while (live) // wave-uniform
+    {
+        const int src = __ffsll((long long)live) - 1;
+        live &= live - 1ull;
+        const V3 ro = mk(__shfl(o.x, src, 64), __shfl(o.y, src, 64), __shfl(o.z, src, 64));
+        const V3 rd = mk(__shfl(d.x, src, 64), __shfl(d.y, src, 64), __shfl(d.z, src, 64));
+        unsigned long long key = ~0ull;
+        for (uint32_t i = (uint32_t)lane; i < S.n_active; i += 64u)
+        {
+            const float t = exact_offer(tab[i], ro, rd);
+            if (t < FLT_MAX)
+            {
+                const unsigned long long k = ((unsigned long long)__float_as_uint(t) << 32) | i; // t > 0: bit order = value order
+                key = k < key ? k : key;
+            }
+        }
+        // the reference flags ~0.5 % of the spheres per ray: walk the few lanes that hold an offer
+        unsigned long long best = ~0ull;
+        unsigned long long offers = __ballot(key != ~0ull);
+        while (offers)
+        {
+            const int l = __ffsll((long long)offers) - 1;
+            offers &= offers - 1ull;
+            const unsigned long long k = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(key >> 32), l) << 32) |
+                                         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, l);
+            best = k < best ? k : best;
+        }
+        if (lane == src && best != ~0ull)
+        {
+            t_max = __uint_as_float((uint32_t)(best >> 32));
+            hit_index = (int)(uint32_t)best;
+        }
+    }
+}
+
 // Attenuation stack.  Small scenes: packed in LDS, three 10-bit sphere indices per word.  Big
 // scenes (> 1023 active spheres): one u32 per entry in a global workspace laid out
 // [entry][global thread] (coalesced); its traffic is nothing next to a 100 k-sphere sweep.
@@ -709,8 +755,10 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t n, const R1FastDiv dv)
 // Returns false for a void slot (pixel of an edge tile that lies outside the image).
 __device__ __forceinline__ bool start_sample(const R1TraceArgs &A, Path &p, uint32_t k)
 {
-    const uint32_t j = fastdiv(k, A.div_full);
+    uint32_t j = fastdiv(k, A.div_full);
     const uint32_t r = k - j * A.full;
+    if (A.tile_order)
+        j = A.tile_order[j]; // queue position -> local tile
     const uint32_t pix = fastdiv(r, A.div_spp);
     const uint32_t s = r - pix * (uint32_t)A.spp;
     const uint32_t ly = fastdiv(pix, A.div_tw);
@@ -928,8 +976,17 @@ __device__ __forceinline__ bool shade_level(const R1TraceArgs &A, Path &p, const
 // ============================================================================================
 // STATS = diagnostic build (variant R1_VARIANT_STATS): same results, plus per-phase cycle and
 // utilisation counters in A.stats; never used by the product path.
+// Waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument): the
+// product kernels are sized by their LDS (tree: 6 workgroups per CU, exhaustive sweep: 5), so their VGPR
+// count has to stay under 512 / 6 -> 80 and 512 / 5 -> 96.
 template <int VARIANT, bool STATS, bool BIG>
-__global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
+struct TraceWaves
+{
+    static constexpr int value = STATS ? 1 : (VARIANT == 4 ? (BIG ? 1 : 6) : (VARIANT == 2 && !BIG ? 5 : 1));
+};
+
+template <int VARIANT, bool STATS, bool BIG>
+__global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::value)) r1_trace_kernel(const R1TraceArgs A)
 {
     typedef typename IdxType<BIG>::type IDX;
     unsigned long long wstat[16];
@@ -938,6 +995,15 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
         for (int i = 0; i < 16; ++i)
             wstat[i] = 0;
         wstat[14] = __builtin_readcyclecounter();
+    }
+    // STATS builds: optional per-wave log {start, queue-empty, end (100 MHz real-time clock), iterations};
+    // its address is handed over in stats[15] (tools/wave_timeline.py)
+    unsigned long long *wave_log = nullptr;
+    unsigned long long log_start = 0, log_exhausted = 0;
+    if (STATS && A.stats)
+    {
+        wave_log = (unsigned long long *)A.stats[15];
+        log_start = __builtin_amdgcn_s_memrealtime();
     }
     __shared__ uint32_t s_stack[BIG ? 1 : R1_STACK_WORDS * R1_BLOCK];
     __shared__ uint32_t s_cand[VARIANT == 2 ? (BIG ? R1_CAND_CAP : R1_BIT_WORDS) * R1_BLOCK : 1];
@@ -962,9 +1028,14 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
     // a wave asks for ~1/(2*waves) of what it last saw remaining, between R1_CHUNK_MIN and
     // R1_CHUNK samples, so that the last waves to finish hold little work.
     uint32_t q_next = 0, q_end = 0;
-    uint32_t q_remaining = A.total_samples;
+    const uint32_t q_total = A.total_samples;
+    uint32_t q_remaining = q_total;
     const uint32_t n_waves2 = 2u * gridDim.x * (R1_BLOCK / 64);
     bool exhausted = false;
+    // sub-queue this wave pulls from (A.nq > 1), wave-uniform
+    // (workgroups b .. b + 7 sit on the eight XCDs and share their sub-queues, so every sub-queue is served from
+    // every XCD: the XCDs of one chip ran this kernel up to 20 % apart in speed, tools/wave_timeline.py)
+    const uint32_t home = A.nq > 1 ? __builtin_amdgcn_readfirstlane(((blockIdx.x >> 3) * (R1_BLOCK / 64) + (threadIdx.x >> 6)) % A.nq) : 0u;
 
     for (;;)
     {
@@ -978,19 +1049,36 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
             {
                 if (exhausted)
                     break;
-                const uint32_t want = min(A.chunk_max, max(A.chunk_min, q_remaining / n_waves2));
-                uint32_t base = 0;
-                if (lane == 0)
-                    base = atomicAdd(A.queue, want);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= A.total_samples)
+                uint32_t want, base = 0;
+                if (A.nq > 1)
                 {
+                    // fixed chunks dealt round-robin to the sub-queues: chunk j of sub-queue `home` is chunk j nq + home
+                    want = A.chunk_max;
+                    if (lane == 0)
+                        base = atomicAdd(A.queue + 32u * home, 1u);
+                    base = (__builtin_amdgcn_readfirstlane(base) * A.nq + home) * want;
+                }
+                else
+                {
+                    want = min(A.chunk_max, max(A.chunk_min, q_remaining / n_waves2));
+                    if (lane == 0)
+                        base = atomicAdd(A.queue, want);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                }
+                if (base >= q_total)
+                {
+                    // No stealing between sub-queues: chunks are dealt round-robin, so the sub-queues run dry together, the
+                    // host gives every sub-queue home waves on every XCD, and looking for leftovers elsewhere costs more than
+                    // it brings (nq failed atomics of ~1 us each at the end of every wave; a one-load scan of the heads
+                    // spilled 50 SGPRs in this loop).
                     exhausted = true;
+                    if (STATS)
+                        log_exhausted = __builtin_amdgcn_s_memrealtime();
                     break;
                 }
                 q_next = base;
-                q_end = min(base + want, A.total_samples);
-                q_remaining = A.total_samples - q_end;
+                q_end = min(base + want, q_total);
+                q_remaining = q_total - q_end;
             }
             const uint32_t avail = q_end - q_next;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
@@ -1035,7 +1123,10 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
         // ---- one color() level: hit test for every live lane (rayweek1.cpp:519) ----
         float t_hit = FLT_MAX;
         int hit = -1;
-        if (VARIANT == 1)
+        const unsigned long long live_now = __ballot(alive);
+        if (!BIG && VARIANT != 1 && exhausted && (uint32_t)__popcll(live_now) <= A.coop_lanes)
+            cooperative_sweep(A.scene, live_now, p.o, p.d, t_hit, hit, lane); // the frame's tail: few paths left in this wave
+        else if (VARIANT == 1)
         {
             if (alive)
                 sweep_reference(A.scene, p.o, p.d, t_hit, hit);
@@ -1084,6 +1175,11 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_trace_kernel(const R1TraceArgs A)
                     c += __shfl_down(c, off, 64);
                 wstat[slots[q]] = c;
             }
+        }
+        if (lane == 0 && wave_log)
+        {
+            unsigned long long *rec = wave_log + 4 * (size_t)(blockIdx.x * (R1_BLOCK / 64) + (threadIdx.x >> 6));
+            rec[0] = log_start, rec[1] = log_exhausted, rec[2] = __builtin_amdgcn_s_memrealtime(), rec[3] = wstat[0];
         }
         if (lane == 0 && A.stats)
         {
@@ -1282,7 +1378,9 @@ extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int 
     // dynamic LDS: the traversal stack of the tree kernels, one entry per inner node on a path
     const size_t trav = (variant == 4 || variant == 5) ? (size_t)args->bvh_depth * R1_BLOCK * sizeof(uint32_t) : 0;
     const bool big = big_in != 0; // 32-bit hit indices, attenuation stack in the global workspace
-    if (variant == 5 && big)
+    if (false)
+        ;
+    else if (variant == 5 && big)
         hipLaunchKernelGGL((r1_trace_kernel<4, true, true>), dim3(blocks), dim3(R1_BLOCK), trav, stream, *args);
     else if (variant == 5)
         hipLaunchKernelGGL((r1_trace_kernel<4, true, false>), dim3(blocks), dim3(R1_BLOCK), trav, stream, *args);
