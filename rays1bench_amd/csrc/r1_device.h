@@ -92,9 +92,6 @@ struct R1TraceArgs
     R1FastDiv div_full, div_spp, div_tw, div_tx; // by full, spp, tile_w, tiles_x
     uint32_t total_samples;      // n_local_tiles * full (queue length)
     uint32_t chunk_min, chunk_max; // samples a wave takes from the queue per atomic (guided: remaining / (2 waves), clamped)
-    const uint32_t *tile_order;  // null: queue position j is local tile j.  Else local tile = tile_order[j]: the order tiles ENTER the
-                                 // queue (costly tiles first, so that long bounce chains start early; r1_capi.cpp).  Storage and
-                                 // seeding follow the tile itself, so the image does not depend on the order.
     uint32_t *queue;             // global sample counter(s) (zeroed before the launch); sub-queue q at queue + 32 q (its own 128-byte line)
     uint32_t nq;                 // 1: one guided queue (chunk_min..chunk_max).  > 1 (latency mode): nq sub-queues of fixed chunks of
                                  // chunk_max slots, chunk c belongs to sub-queue c % nq and a wave only pulls from sub-queue wave % nq:

@@ -755,10 +755,8 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t n, const R1FastDiv dv)
 // Returns false for a void slot (pixel of an edge tile that lies outside the image).
 __device__ __forceinline__ bool start_sample(const R1TraceArgs &A, Path &p, uint32_t k)
 {
-    uint32_t j = fastdiv(k, A.div_full);
+    const uint32_t j = fastdiv(k, A.div_full);
     const uint32_t r = k - j * A.full;
-    if (A.tile_order)
-        j = A.tile_order[j]; // queue position -> local tile
     const uint32_t pix = fastdiv(r, A.div_spp);
     const uint32_t s = r - pix * (uint32_t)A.spp;
     const uint32_t ly = fastdiv(pix, A.div_tw);
@@ -985,7 +983,10 @@ struct TraceWaves
     static constexpr int value = STATS ? 1 : (VARIANT == 4 ? (BIG ? 1 : 6) : (VARIANT == 2 && !BIG ? 5 : 1));
 };
 
-template <int VARIANT, bool STATS, bool BIG>
+// LAT = latency-mode build (the synchronous entry points: one frame, full grid): sub-queues and
+// the cooperative tail are compiled in.  The throughput-mode build (frames in flight, few
+// long-lived waves per frame) leaves them out: they cost it registers and bring it nothing.
+template <int VARIANT, bool STATS, bool BIG, bool LAT>
 __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::value)) r1_trace_kernel(const R1TraceArgs A)
 {
     typedef typename IdxType<BIG>::type IDX;
@@ -1035,7 +1036,7 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
     // sub-queue this wave pulls from (A.nq > 1), wave-uniform
     // (workgroups b .. b + 7 sit on the eight XCDs and share their sub-queues, so every sub-queue is served from
     // every XCD: the XCDs of one chip ran this kernel up to 20 % apart in speed, tools/wave_timeline.py)
-    const uint32_t home = A.nq > 1 ? __builtin_amdgcn_readfirstlane(((blockIdx.x >> 3) * (R1_BLOCK / 64) + (threadIdx.x >> 6)) % A.nq) : 0u;
+    const uint32_t home = LAT && A.nq > 1 ? __builtin_amdgcn_readfirstlane(((blockIdx.x >> 3) * (R1_BLOCK / 64) + (threadIdx.x >> 6)) % A.nq) : 0u;
 
     for (;;)
     {
@@ -1050,7 +1051,7 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
                 if (exhausted)
                     break;
                 uint32_t want, base = 0;
-                if (A.nq > 1)
+                if (LAT && A.nq > 1)
                 {
                     // fixed chunks dealt round-robin to the sub-queues: chunk j of sub-queue `home` is chunk j nq + home
                     want = A.chunk_max;
@@ -1124,7 +1125,7 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
         float t_hit = FLT_MAX;
         int hit = -1;
         const unsigned long long live_now = __ballot(alive);
-        if (!BIG && VARIANT != 1 && exhausted && (uint32_t)__popcll(live_now) <= A.coop_lanes)
+        if (LAT && !BIG && VARIANT != 1 && exhausted && (uint32_t)__popcll(live_now) <= A.coop_lanes)
             cooperative_sweep(A.scene, live_now, p.o, p.d, t_hit, hit, lane); // the frame's tail: few paths left in this wave
         else if (VARIANT == 1)
         {
@@ -1373,31 +1374,36 @@ __global__ void __launch_bounds__(256)
 
 // ---- launchers (called from r1_capi.cpp) -----------------------------------------------------
 
-extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int big_in, int blocks, hipStream_t stream)
+extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int big_in, int latency, int blocks, hipStream_t stream)
 {
     // dynamic LDS: the traversal stack of the tree kernels, one entry per inner node on a path
     const size_t trav = (variant == 4 || variant == 5) ? (size_t)args->bvh_depth * R1_BLOCK * sizeof(uint32_t) : 0;
     const bool big = big_in != 0; // 32-bit hit indices, attenuation stack in the global workspace
-    if (false)
-        ;
-    else if (variant == 5 && big)
-        hipLaunchKernelGGL((r1_trace_kernel<4, true, true>), dim3(blocks), dim3(R1_BLOCK), trav, stream, *args);
+    const bool lat = latency != 0 && !big;
+#define R1_GO(V, S, B, L) hipLaunchKernelGGL((r1_trace_kernel<V, S, B, L>), dim3(blocks), dim3(R1_BLOCK), (V) == 4 ? trav : 0, stream, *args)
+    if (variant == 5 && big)
+        R1_GO(4, true, true, false);
     else if (variant == 5)
-        hipLaunchKernelGGL((r1_trace_kernel<4, true, false>), dim3(blocks), dim3(R1_BLOCK), trav, stream, *args);
+        R1_GO(4, true, false, true); // the diagnostic build follows the latency-mode kernel (it is only run synchronously)
     else if (variant == 4 && big)
-        hipLaunchKernelGGL((r1_trace_kernel<4, false, true>), dim3(blocks), dim3(R1_BLOCK), trav, stream, *args);
+        R1_GO(4, false, true, false);
+    else if (variant == 4 && lat)
+        R1_GO(4, false, false, true);
     else if (variant == 4)
-        hipLaunchKernelGGL((r1_trace_kernel<4, false, false>), dim3(blocks), dim3(R1_BLOCK), trav, stream, *args);
+        R1_GO(4, false, false, false);
     else if (variant == 1 && big)
-        hipLaunchKernelGGL((r1_trace_kernel<1, false, true>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
+        R1_GO(1, false, true, false);
     else if (variant == 1)
-        hipLaunchKernelGGL((r1_trace_kernel<1, false, false>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
+        R1_GO(1, false, false, false);
     else if (variant == 3 && !big)
-        hipLaunchKernelGGL((r1_trace_kernel<2, true, false>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
+        R1_GO(2, true, false, true);
     else if (big)
-        hipLaunchKernelGGL((r1_trace_kernel<2, false, true>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
+        R1_GO(2, false, true, false);
+    else if (lat)
+        R1_GO(2, false, false, true);
     else
-        hipLaunchKernelGGL((r1_trace_kernel<2, false, false>), dim3(blocks), dim3(R1_BLOCK), 0, stream, *args);
+        R1_GO(2, false, false, false);
+#undef R1_GO
     return hipGetLastError();
 }
 
@@ -1438,21 +1444,23 @@ extern "C" hipError_t r1_launch_assemble(const void *blocks, void *rgb, int widt
 
 extern "C" hipError_t r1_trace_occupancy(int variant, int big, size_t dyn_lds, int *blocks_per_cu)
 {
+#define R1_OCC(V, S, B, L) hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<V, S, B, L>, R1_BLOCK, (V) == 4 ? dyn_lds : 0)
     if (variant == 5 && big)
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<4, true, true>, R1_BLOCK, dyn_lds);
+        return R1_OCC(4, true, true, false);
     if (variant == 5)
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<4, true, false>, R1_BLOCK, dyn_lds);
+        return R1_OCC(4, true, false, true);
     if (variant == 4 && big)
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<4, false, true>, R1_BLOCK, dyn_lds);
+        return R1_OCC(4, false, true, false);
     if (variant == 4)
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<4, false, false>, R1_BLOCK, dyn_lds);
+        return R1_OCC(4, false, false, true);
     if (variant == 1 && big)
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<1, false, true>, R1_BLOCK, 0);
+        return R1_OCC(1, false, true, false);
     if (variant == 1)
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<1, false, false>, R1_BLOCK, 0);
+        return R1_OCC(1, false, false, false);
     if (variant == 3 && !big)
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<2, true, false>, R1_BLOCK, 0);
+        return R1_OCC(2, true, false, true);
     if (big)
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<2, false, true>, R1_BLOCK, 0);
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<2, false, false>, R1_BLOCK, 0);
+        return R1_OCC(2, false, true, false);
+    return R1_OCC(2, false, false, true);
+#undef R1_OCC
 }
