@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define R1_ABI_VERSION 1
+#define R1_ABI_VERSION 2
 
 enum
 {
@@ -181,6 +181,10 @@ size_t r1_shard_block_bytes(const r1_params *params);
  * flight (one context + stream per frame in flight). */
 int r1_render_shard_device(r1_context *ctx, const r1_params *params, void *d_block, void *d_num_rays, void *hip_stream);
 
+/* Same outputs, sized for latency instead: ONE frame whose result the caller waits for (the full
+ * persistent grid and the latency-mode kernels of r1_render).  Used by r1_multi_render. */
+int r1_render_shard_device_once(r1_context *ctx, const r1_params *params, void *d_block, void *d_num_rays, void *hip_stream);
+
 /* Scatters `num_shards` gathered blocks (concatenated in shard order, device memory)
  * into the row-major image d_rgb (width*height*3 bytes, device memory). */
 int r1_assemble_device(r1_context *ctx, const r1_params *params, const void *d_blocks, void *d_rgb, void *hip_stream);
@@ -232,6 +236,25 @@ typedef struct r1_launch_info
     int32_t bvh_depth;      /* inner nodes on the longest root-to-leaf path       */
 } r1_launch_info;
 int r1_last_launch_info(r1_context *ctx, r1_launch_info *out);
+
+/* ---- one process, N GPUs: tile split + one RCCL all-gather per frame --------------------- */
+
+/* The multi-GPU form of benchmark()'s join (rayweek1.cpp:804-813, :773-775) behind ONE call, so that
+ * the reference's four-argument benchmark() stays a single function: tile t is
+ * rendered by device t % N (r1_params.shard / num_shards are set by the library), every device's
+ * record (dense tile block + its uint64 ray count) goes through one ncclAllGather over xGMI, device 0
+ * assembles the row-major image and copies it to the host once.  RCCL is loaded at run time
+ * (librccl.so.1); r1_multi_create fails with R1_ENODEVICE where it is missing — no fallback.
+ * `devices` = N distinct HIP device ordinals (NULL: 0..N-1).  One call at a time per r1_multi. */
+typedef struct r1_multi r1_multi;
+int r1_multi_create(int32_t n_devices, const int32_t *devices, r1_multi **out);
+void r1_multi_destroy(r1_multi *m);
+int r1_multi_set_scene(r1_multi *m, const r1_scene *scene, const r1_camera *camera);
+/* rgb_out / num_rays_out as r1_render (whole frame); device_seconds_out (optional): render + gather
+ * on the slowest device, from HIP events. */
+int r1_multi_render(r1_multi *m, const r1_params *params, uint8_t *rgb_out, uint64_t *num_rays_out, double *device_seconds_out);
+/* Facts for reports: device count, RCCL version code (ncclGetVersion), launch info of the first device. */
+int r1_multi_info(r1_multi *m, int32_t *n_devices, int32_t *rccl_version, r1_launch_info *first_device);
 
 /* ---- host-side helpers of the drop-in (no GPU needed) ------------------------------ */
 

@@ -87,6 +87,12 @@ SYMBOLS = [
     ("r1_tile_count", C.c_int, [C.POINTER(Params), _i32p, _i32p]),
     ("r1_shard_block_bytes", C.c_size_t, [C.POINTER(Params)]),
     ("r1_render_shard_device", C.c_int, [_ctx, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("r1_render_shard_device_once", C.c_int, [_ctx, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("r1_multi_create", C.c_int, [C.c_int32, _i32p, C.POINTER(C.c_void_p)]),
+    ("r1_multi_destroy", None, [C.c_void_p]),
+    ("r1_multi_set_scene", C.c_int, [C.c_void_p, C.POINTER(CScene), C.POINTER(CCamera)]),
+    ("r1_multi_render", C.c_int, [C.c_void_p, C.POINTER(Params), _u8p, _u64p, _dblp]),
+    ("r1_multi_info", C.c_int, [C.c_void_p, _i32p, _i32p, C.POINTER(LaunchInfo)]),
     ("r1_assemble_device", C.c_int, [_ctx, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p]),
     ("r1_assemble_device_strided", C.c_int, [_ctx, C.POINTER(Params), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     ("r1_sync", C.c_int, [_ctx]),
@@ -279,6 +285,40 @@ class Renderer:
         if self._c:
             lib().r1_destroy(self._c)
             self._c = _ctx()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiRenderer:
+    """r1_multi: one process, N GPUs, tile split + one RCCL all-gather per frame (include/rays1.h)."""
+
+    def __init__(self, devices):
+        devs = (C.c_int32 * len(devices))(*devices)
+        self._m = C.c_void_p()
+        _check(lib().r1_multi_create(len(devices), devs, C.byref(self._m)))
+
+    def set_scene(self, scene):
+        _check(lib().r1_multi_set_scene(self._m, scene.spheres, scene.camera))
+
+    def render(self, params):
+        img = np.zeros((params.height, params.width, 3), np.uint8)
+        rays, secs = C.c_uint64(), C.c_double()
+        _check(lib().r1_multi_render(self._m, C.byref(params), img.ctypes.data_as(_u8p), C.byref(rays), C.byref(secs)))
+        return img, int(rays.value), float(secs.value)
+
+    def info(self):
+        n, v, li = C.c_int32(), C.c_int32(), LaunchInfo()
+        _check(lib().r1_multi_info(self._m, C.byref(n), C.byref(v), C.byref(li)))
+        return {"devices": int(n.value), "rccl_version": int(v.value), "first_device": {k: int(getattr(li, k)) for k, _ in LaunchInfo._fields_}}
+
+    def close(self):
+        if self._m:
+            lib().r1_multi_destroy(self._m)
+            self._m = C.c_void_p()
 
     def __del__(self):
         try:

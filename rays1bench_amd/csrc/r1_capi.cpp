@@ -941,6 +941,17 @@ extern "C" int r1_render_shard_device(r1_context *c, const r1_params *p, void *d
     return enqueue_frame(c, p, d_block, 1, d_num_rays, st, true);
 }
 
+extern "C" int r1_render_shard_device_once(r1_context *c, const r1_params *p, void *d_block, void *d_num_rays, void *hip_stream)
+{
+    if (!c || !p || !d_block || !d_num_rays)
+    {
+        r1_set_error("r1_render_shard_device_once: null argument");
+        return R1_EINVAL;
+    }
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    return enqueue_frame(c, p, d_block, 1, d_num_rays, st, false);
+}
+
 extern "C" int r1_assemble_device_strided(r1_context *c, const r1_params *p, const void *d_blocks, size_t shard_stride_bytes, void *d_rgb,
                                           void *hip_stream)
 {

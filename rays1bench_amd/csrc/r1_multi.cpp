@@ -1,0 +1,343 @@
+// r1_multi.cpp — one process, N GPUs: the frame's tiles split over N devices (tile t -> device
+// t % N) and ONE RCCL all-gather of the per-device records (dense tile block + 8-byte ray count)
+// at the end of the frame; the row-major image is assembled on device 0 and copied to the host
+// once.  This is the multi-GPU form of benchmark()'s join (rayweek1.cpp:804-813: the threads'
+// `out_num_rays` are summed and every tile has been written to the one pixel buffer,
+// rayweek1.cpp:773-775) that keeps the reference's four-argument benchmark() a single call:
+// SURVEY.md §8e "single-process-multi-GPU (ncclCommInitAll) keeps the benchmark() signature
+// intact".  bench.py's N-process form (torch.distributed) uses the same record layout.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1): librays1.so keeps loading where RCCL is
+// not installed, and inside a process that already carries a copy (torch bundles one) the same
+// library is used instead of a second one.  There is no fallback: r1_multi_create fails if RCCL
+// or the devices are not there.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "../../include/rays1.h"
+
+extern "C" void r1_set_error(const char *fmt, ...);
+
+namespace
+{
+
+// the slice of rccl.h this file needs (opaque communicator, result code 0 = success)
+typedef struct ncclComm *ncclComm_t;
+typedef int ncclResult_t;
+enum
+{
+    R1_NCCL_UINT8 = 1 // ncclUint8 / ncclChar's unsigned twin in rccl.h's ncclDataType_t
+};
+
+struct Rccl
+{
+    void *lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    int (*GetVersion)(int *) = nullptr;
+};
+
+bool load_rccl(Rccl &r)
+{
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names)
+        if ((r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL)))
+            break;
+    if (!r.lib)
+    {
+        r1_set_error("r1_multi_create: cannot load librccl.so.1 (%s)", dlerror());
+        return false;
+    }
+#define R1_SYM(field, name)                                                                                            \
+    if (!(*(void **)(&r.field) = dlsym(r.lib, name)))                                                                  \
+    {                                                                                                                  \
+        r1_set_error("r1_multi_create: librccl has no %s", name);                                                      \
+        return false;                                                                                                  \
+    }
+    R1_SYM(CommInitAll, "ncclCommInitAll")
+    R1_SYM(CommDestroy, "ncclCommDestroy")
+    R1_SYM(AllGather, "ncclAllGather")
+    R1_SYM(GroupStart, "ncclGroupStart")
+    R1_SYM(GroupEnd, "ncclGroupEnd")
+    R1_SYM(GetErrorString, "ncclGetErrorString")
+    R1_SYM(GetVersion, "ncclGetVersion")
+#undef R1_SYM
+    return true;
+}
+
+} // namespace
+
+struct r1_multi
+{
+    Rccl rccl;
+    int n = 0;
+    std::vector<int> device;
+    std::vector<r1_context *> ctx;
+    std::vector<ncclComm_t> comm;
+    std::vector<hipStream_t> stream;
+    std::vector<void *> d_record, d_gathered; // per device: its record, all records
+    void *d_rgb = nullptr;                      // device 0: the assembled image
+    size_t record_cap = 0, rgb_cap = 0;
+    std::vector<hipEvent_t> ev0, ev1;
+    int rccl_version = 0;
+};
+
+#define R1M_HIP(call)                                                                                                  \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        hipError_t e_ = (call);                                                                                        \
+        if (e_ != hipSuccess)                                                                                          \
+        {                                                                                                              \
+            r1_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);                   \
+            return e_ == hipErrorOutOfMemory ? R1_ENOMEM : R1_EHIP;                                                    \
+        }                                                                                                              \
+    } while (0)
+#define R1M_NCCL(m, call)                                                                                              \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        ncclResult_t r_ = (call);                                                                                      \
+        if (r_ != 0)                                                                                                   \
+        {                                                                                                              \
+            r1_set_error("%s failed: %s (%s:%d)", #call, (m)->rccl.GetErrorString(r_), __FILE__, __LINE__);            \
+            return R1_EHIP;                                                                                            \
+        }                                                                                                              \
+    } while (0)
+
+extern "C" void r1_multi_destroy(r1_multi *m)
+{
+    if (!m)
+        return;
+    for (int i = 0; i < (int)m->ctx.size(); ++i)
+    {
+        (void)hipSetDevice(m->device[i]);
+        if (i < (int)m->stream.size() && m->stream[i])
+            (void)hipStreamSynchronize(m->stream[i]);
+        if (i < (int)m->comm.size() && m->comm[i])
+            (void)m->rccl.CommDestroy(m->comm[i]);
+        if (i < (int)m->d_record.size() && m->d_record[i])
+            (void)hipFree(m->d_record[i]);
+        if (i < (int)m->d_gathered.size() && m->d_gathered[i])
+            (void)hipFree(m->d_gathered[i]);
+        if (i == 0 && m->d_rgb)
+            (void)hipFree(m->d_rgb);
+        if (i < (int)m->ev0.size() && m->ev0[i])
+            (void)hipEventDestroy(m->ev0[i]);
+        if (i < (int)m->ev1.size() && m->ev1[i])
+            (void)hipEventDestroy(m->ev1[i]);
+        if (i < (int)m->stream.size() && m->stream[i])
+            (void)hipStreamDestroy(m->stream[i]);
+        r1_destroy(m->ctx[i]);
+    }
+    // the library handle stays open: other communicators of the process may live in it
+    delete m;
+}
+
+extern "C" int r1_multi_create(int32_t n_devices, const int32_t *devices, r1_multi **out)
+{
+    if (!out || n_devices < 1 || n_devices > 64)
+    {
+        r1_set_error("r1_multi_create: bad argument");
+        return R1_EINVAL;
+    }
+    *out = nullptr;
+    const int visible = r1_device_count();
+    if (visible <= 0)
+        return R1_ENODEVICE;
+    r1_multi *m = new (std::nothrow) r1_multi();
+    if (!m)
+        return R1_ENOMEM;
+    m->n = n_devices;
+    for (int i = 0; i < n_devices; ++i)
+    {
+        const int d = devices ? devices[i] : i;
+        for (int k = 0; k < i; ++k)
+            if (m->device[k] == d)
+            {
+                r1_set_error("r1_multi_create: device %d listed twice (an RCCL communicator needs distinct devices)", d);
+                delete m;
+                return R1_EINVAL;
+            }
+        if (d < 0 || d >= visible)
+        {
+            r1_set_error("r1_multi_create: device %d out of range (0..%d)", d, visible - 1);
+            delete m;
+            return R1_EINVAL;
+        }
+        m->device.push_back(d);
+    }
+    if (!load_rccl(m->rccl))
+    {
+        delete m;
+        return R1_ENODEVICE;
+    }
+    (void)m->rccl.GetVersion(&m->rccl_version);
+    m->comm.assign(n_devices, nullptr);
+    m->stream.assign(n_devices, nullptr);
+    m->d_record.assign(n_devices, nullptr);
+    m->d_gathered.assign(n_devices, nullptr);
+    m->ev0.assign(n_devices, nullptr);
+    m->ev1.assign(n_devices, nullptr);
+    int rc = R1_OK;
+    for (int i = 0; i < n_devices && rc == R1_OK; ++i)
+    {
+        r1_context *c = nullptr;
+        rc = r1_create(m->device[i], &c);
+        if (rc == R1_OK)
+            m->ctx.push_back(c);
+    }
+    auto fail = [&](int code) {
+        r1_multi_destroy(m);
+        return code;
+    };
+    if (rc != R1_OK)
+        return fail(rc);
+    for (int i = 0; i < n_devices; ++i)
+    {
+        if (hipSetDevice(m->device[i]) != hipSuccess || hipStreamCreateWithFlags(&m->stream[i], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreate(&m->ev0[i]) != hipSuccess || hipEventCreate(&m->ev1[i]) != hipSuccess)
+        {
+            r1_set_error("r1_multi_create: stream/event creation failed on device %d", m->device[i]);
+            return fail(R1_EHIP);
+        }
+    }
+    const ncclResult_t nr = m->rccl.CommInitAll(m->comm.data(), n_devices, m->device.data());
+    if (nr != 0)
+    {
+        r1_set_error("ncclCommInitAll(%d devices) failed: %s", n_devices, m->rccl.GetErrorString(nr));
+        return fail(R1_EHIP);
+    }
+    *out = m;
+    return R1_OK;
+}
+
+extern "C" int r1_multi_set_scene(r1_multi *m, const r1_scene *scene, const r1_camera *camera)
+{
+    if (!m)
+        return R1_EINVAL;
+    for (int i = 0; i < m->n; ++i)
+    {
+        const int rc = r1_set_scene(m->ctx[i], scene, camera); // replicated: <= 14 KB of tables
+        if (rc != R1_OK)
+            return rc;
+    }
+    return R1_OK;
+}
+
+extern "C" int r1_multi_render(r1_multi *m, const r1_params *params, uint8_t *rgb_out, uint64_t *num_rays_out, double *device_seconds_out)
+{
+    if (!m || !params || !rgb_out)
+    {
+        r1_set_error("r1_multi_render: null argument");
+        return R1_EINVAL;
+    }
+    r1_params p = *params;
+    p.shard = 0, p.num_shards = m->n;
+    const size_t block = r1_shard_block_bytes(&p);
+    if (block == 0)
+        return R1_EINVAL;
+    const size_t record = block + 8; // + the shard's uint64 ray count: pixels and counts travel in one collective
+    const size_t rgb_bytes = (size_t)p.width * p.height * 3;
+    if (record > m->record_cap)
+    {
+        for (int i = 0; i < m->n; ++i)
+        {
+            R1M_HIP(hipSetDevice(m->device[i]));
+            R1M_HIP(hipStreamSynchronize(m->stream[i]));
+            if (m->d_record[i])
+                R1M_HIP(hipFree(m->d_record[i]));
+            if (m->d_gathered[i])
+                R1M_HIP(hipFree(m->d_gathered[i]));
+            m->d_record[i] = m->d_gathered[i] = nullptr;
+            R1M_HIP(hipMalloc(&m->d_record[i], record));
+            R1M_HIP(hipMalloc(&m->d_gathered[i], record * (size_t)m->n));
+        }
+        m->record_cap = record;
+    }
+    if (rgb_bytes > m->rgb_cap)
+    {
+        R1M_HIP(hipSetDevice(m->device[0]));
+        R1M_HIP(hipStreamSynchronize(m->stream[0]));
+        if (m->d_rgb)
+            R1M_HIP(hipFree(m->d_rgb));
+        m->d_rgb = nullptr;
+        R1M_HIP(hipMalloc(&m->d_rgb, rgb_bytes));
+        m->rgb_cap = rgb_bytes;
+    }
+    // 1. every device traces + resolves its tiles into its record (latency-mode kernels: one frame, the caller waits)
+    for (int i = 0; i < m->n; ++i)
+    {
+        r1_params q = p;
+        q.shard = i;
+        R1M_HIP(hipSetDevice(m->device[i]));
+        R1M_HIP(hipEventRecord(m->ev0[i], m->stream[i]));
+        const int rc = r1_render_shard_device_once(m->ctx[i], &q, m->d_record[i], (char *)m->d_record[i] + block, m->stream[i]);
+        if (rc != R1_OK)
+            return rc;
+    }
+    // 2. the one exchange step of the frame: all-gather of the records over xGMI
+    R1M_NCCL(m, m->rccl.GroupStart());
+    for (int i = 0; i < m->n; ++i)
+        R1M_NCCL(m, m->rccl.AllGather(m->d_record[i], m->d_gathered[i], record, R1_NCCL_UINT8, m->comm[i], m->stream[i]));
+    R1M_NCCL(m, m->rccl.GroupEnd());
+    for (int i = 0; i < m->n; ++i)
+    {
+        R1M_HIP(hipSetDevice(m->device[i]));
+        R1M_HIP(hipEventRecord(m->ev1[i], m->stream[i]));
+    }
+    // 3. device 0 scatters the gathered tiles into the row-major image; one copy to the host (+ the N counts)
+    R1M_HIP(hipSetDevice(m->device[0]));
+    int rc = r1_assemble_device_strided(m->ctx[0], &p, m->d_gathered[0], record, m->d_rgb, m->stream[0]);
+    if (rc != R1_OK)
+        return rc;
+    std::vector<uint64_t> counts((size_t)m->n, 0);
+    R1M_HIP(hipMemcpyAsync(rgb_out, m->d_rgb, rgb_bytes, hipMemcpyDeviceToHost, m->stream[0]));
+    R1M_HIP(hipMemcpy2DAsync(counts.data(), 8, (char *)m->d_gathered[0] + block, record, 8, (size_t)m->n, hipMemcpyDeviceToHost, m->stream[0]));
+    R1M_HIP(hipStreamSynchronize(m->stream[0]));
+    for (int i = 1; i < m->n; ++i) // the other devices' gathers are complete before their streams are reused
+    {
+        R1M_HIP(hipSetDevice(m->device[i]));
+        R1M_HIP(hipStreamSynchronize(m->stream[i]));
+    }
+    uint64_t rays = 0;
+    for (uint64_t c : counts)
+        rays += c; // rayweek1.cpp:809-813
+    if (num_rays_out)
+        *num_rays_out = rays;
+    if (device_seconds_out)
+    {
+        double worst = 0;
+        for (int i = 0; i < m->n; ++i)
+        {
+            float ms = 0;
+            R1M_HIP(hipSetDevice(m->device[i]));
+            R1M_HIP(hipEventElapsedTime(&ms, m->ev0[i], m->ev1[i]));
+            worst = ms > worst ? ms : worst;
+        }
+        *device_seconds_out = worst * 1e-3; // render + gather, slowest device
+    }
+    return R1_OK;
+}
+
+extern "C" int r1_multi_info(r1_multi *m, int32_t *n_devices, int32_t *rccl_version, r1_launch_info *first_device)
+{
+    if (!m)
+        return R1_EINVAL;
+    if (n_devices)
+        *n_devices = m->n;
+    if (rccl_version)
+        *rccl_version = m->rccl_version;
+    if (first_device)
+        return r1_last_launch_info(m->ctx[0], first_device);
+    return R1_OK;
+}

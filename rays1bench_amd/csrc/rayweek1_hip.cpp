@@ -12,10 +12,14 @@
 //     --width W --height H --spp S --seed N --device D --devices N --variant V
 //       (V = R1_VARIANT_*: 0 default, 1 reference-form sweep, 2 exhaustive sweep, 4 box tree, 6 wavefront)
 // Defaults are the reference's multi-threaded defaults: 1280x720, 250 spp.
-// --devices N splits the frame over N HIP devices inside this one process (one host thread
-// and one r1_context per device, tile t -> device t % N, each device writes its own tiles of
-// the caller's pixel buffer): the in-process twin of the reference's thread pool
-// (rayweek1.cpp:785-842).  The RCCL-gather variant (one process per GPU) is bench.py's.
+// --devices N splits the frame over N HIP devices inside this one process, tile t -> device
+// t % N (the in-process twin of the reference's thread pool, rayweek1.cpp:785-842):
+//     --gather rccl (default when the N devices are distinct GPUs): r1_multi_render — every device
+//         renders its tiles, ONE ncclAllGather of the tile blocks + ray counts over xGMI, device 0
+//         assembles the image and copies it to the host once (the join of rayweek1.cpp:804-813)
+//     --gather host: one host thread + r1_context per device, each device copies its own tiles
+//         into the caller's pixel buffer (also works oversubscribed: N contexts on fewer GPUs)
+// bench.py's one-process-per-GPU form (torch.distributed) gathers the same records.
 
 #include <stdint.h>
 #include <stdio.h>
@@ -53,7 +57,9 @@ static uint32_t g_seed = 10001;
 static int g_device = 0;
 static int g_variant = R1_VARIANT_DEFAULT;
 static int g_devices = 1;
-static std::vector<r1_context *> g_ctx; // one per device in use
+static std::vector<r1_context *> g_ctx; // one per device in use (--gather host)
+static r1_multi *g_multi = nullptr;     // --gather rccl
+static int g_gather = -1;               // -1 auto, 0 host, 1 rccl
 static std::vector<double> g_device_seconds; // per benchmark() call, for the JSON record
 static r1_launch_info g_last_info;
 
@@ -99,6 +105,47 @@ RESULT benchmark(Scene *scene, Pix *pixels, bool write_tga, const char *scene_na
     p.tile_w = 32, p.tile_h = 32; // rayweek1.cpp:855-856
     p.shard = 0, p.num_shards = 1;
     p.variant = g_variant;
+
+    if (g_multi)
+    {
+        // tile split over the devices + one RCCL all-gather, behind one call
+        double device_seconds = 0;
+        int rc = r1_multi_set_scene(g_multi, scene->hitables, scene->camera);
+        if (rc == R1_OK)
+            rc = r1_multi_render(g_multi, &p, &pixels[0].r, &result.num_rays, &device_seconds);
+        if (rc != R1_OK)
+        {
+            fprintf(stderr, "%s: render failed (%d): %s\n", scene_name, rc, r1_last_error());
+            result.num_rays = 0;
+            g_device_seconds.push_back(0.0);
+            delete scene;
+            return result;
+        }
+        result.elapsed_seconds = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count(); // :891
+        int32_t nd = 0, ver = 0;
+        r1_launch_info li;
+        memset(&li, 0, sizeof(li));
+        r1_multi_info(g_multi, &nd, &ver, &li);
+        g_last_info = li;
+        g_device_seconds.push_back(device_seconds);
+        printf("%s\n", scene_name);
+        printf("elapsed time:   %.3fs\n", result.elapsed_seconds);
+        printf("total samples:  %llu\n", (unsigned long long)((uint64_t)g_screen_w * g_screen_h * g_spp));
+        printf("total rays:     %llu\n", (unsigned long long)result.num_rays);
+        printf("mrays/s:        %0.2f\n", result.get_mrays_per_sec());
+        printf("devices:        %d (first hip:%d, %d CUs, %d workgroups x %d threads), gather: RCCL %d all-gather\n", nd, g_device, li.compute_units,
+               li.blocks, li.threads_per_block, ver);
+        printf("device time:    %.3fms (%0.2f mrays/s)\n", device_seconds * 1e3, device_seconds ? result.num_rays / device_seconds / 1e6 : 0.0);
+        printf("\n");
+        delete scene; // rayweek1.cpp:905
+        if (write_tga)
+        {
+            char filename[128];
+            snprintf(filename, sizeof(filename), "out_%s.tga", scene_name);
+            r1_tga_write_rgb24(filename, g_screen_w, g_screen_h, &pixels[0].r);
+        }
+        return result;
+    }
 
     // one host thread per device; with one device this is a plain call
     const int nd = (int)g_ctx.size();
@@ -202,7 +249,7 @@ static void log_json(const char *version, const char *scene, const RESULT *resul
     uint64_t rays = 0;
     const size_t first = g_device_seconds.size() - (size_t)num_runs;
     fprintf(f, "{\"version\": \"%s\", \"scene\": \"%s\", \"width\": %d, \"height\": %d, \"spp\": %d, \"devices\": %d,\n \"runs\": [", version, scene,
-            g_screen_w, g_screen_h, g_spp, (int)g_ctx.size());
+            g_screen_w, g_screen_h, g_spp, g_devices);
     for (int i = 0; i < num_runs; ++i)
     {
         fprintf(f, "%s{\"elapsed_seconds\": %.6f, \"num_rays\": %llu, \"device_seconds\": %.6f}", i ? ", " : "", results[i].elapsed_seconds,
@@ -214,7 +261,7 @@ static void log_json(const char *version, const char *scene, const RESULT *resul
     fprintf(f, "],\n \"mrays_per_s\": %.3f, \"device_mrays_per_s\": %.3f, \"spheres_padded\": %d, \"spheres_active\": %d,\n", el > 0 ? rays / el / 1e6 : 0.0,
             rays_per_dev_s / 1e6, g_last_info.spheres_padded, g_last_info.spheres_active);
     fprintf(f, " \"algorithmic_bytes_per_ray\": %.0f, \"hbm_algorithmic_fraction_of_8TBs\": %.4f, \"fp32_vector_fraction_of_157TFs\": %.4f}\n", per_ray,
-            rays_per_dev_s * per_ray / 8.0e12 / (double)g_ctx.size(), rays_per_dev_s * per_ray / 157.3e12 / (double)g_ctx.size());
+            rays_per_dev_s * per_ray / 8.0e12 / (double)g_devices, rays_per_dev_s * per_ray / 157.3e12 / (double)g_devices);
     fclose(f);
 }
 
@@ -251,17 +298,35 @@ int main(int argc, const char *argv[])
             g_devices = atoi(argv[++i]);
         else if (strcmp(argv[i], "--variant") == 0 && i + 1 < argc)
             g_variant = atoi(argv[++i]);
+        else if (strcmp(argv[i], "--gather") == 0 && i + 1 < argc)
+        {
+            const char *g = argv[++i];
+            g_gather = strcmp(g, "rccl") == 0 ? 1 : (strcmp(g, "host") == 0 ? 0 : -2);
+        }
     }
-    if (g_screen_w <= 0 || g_screen_h <= 0 || g_spp <= 0 || g_devices < 1 || g_devices > 64)
+    if (g_screen_w <= 0 || g_screen_h <= 0 || g_spp <= 0 || g_devices < 1 || g_devices > 64 || g_gather == -2)
     {
-        fprintf(stderr, "bad --width/--height/--spp/--devices\n");
+        fprintf(stderr, "bad --width/--height/--spp/--devices/--gather\n");
         return 1;
     }
 
     // HIP context creation stays outside the timed region and is shared by all -n runs.
     // Devices wrap around the visible ones, so --devices 2 also works (oversubscribed) on one GPU.
     const int visible = r1_device_count();
-    for (int i = 0; i < g_devices; ++i)
+    if (g_gather == -1)
+        g_gather = g_devices > 1 && g_device + g_devices <= visible ? 1 : 0; // RCCL needs distinct devices
+    if (g_gather == 1)
+    {
+        std::vector<int32_t> devs;
+        for (int i = 0; i < g_devices; ++i)
+            devs.push_back(g_device + i);
+        if (visible <= 0 || r1_multi_create(g_devices, devs.data(), &g_multi) != R1_OK)
+        {
+            fprintf(stderr, "cannot create the RCCL device group: %s\n", r1_last_error());
+            return 2;
+        }
+    }
+    for (int i = 0; i < g_devices && !g_multi; ++i)
     {
         r1_context *c = nullptr;
         if (visible <= 0 || r1_create((g_device + i) % visible, &c) != R1_OK)
@@ -295,5 +360,6 @@ int main(int argc, const char *argv[])
     delete[] pixels;
     for (r1_context *c : g_ctx)
         r1_destroy(c);
+    r1_multi_destroy(g_multi);
     return 0;
 }

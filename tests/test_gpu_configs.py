@@ -325,3 +325,51 @@ def test_mismatched_radius_arrays_stay_conservative(renderer):
         sa.arrays["inv_radius"][5] = np.float32(np.nan)
         renderer.set_scene_raw(_cscene(sa), _ccamera(sa))
     assert e.value.code == binding.R1_EINVAL
+
+
+# ---- one process, N GPUs: r1_multi (RCCL all-gather inside the C++ host path) ----------------------
+
+
+def test_r1_multi_one_rank_communicator_equals_the_plain_render(renderer):
+    """r1_multi_render = every device renders its tiles -> ONE ncclAllGather of (tile block + ray count)
+    -> assemble on device 0 -> one copy to the host (rayweek1.cpp:804-813 is the join it stands for).  On a
+    one-GPU box the communicator has one rank (valid in RCCL): the whole path runs, collective included."""
+    m = binding.MultiRenderer([0])
+    try:
+        info = m.info()
+        assert info["devices"] == 1 and info["rccl_version"] > 0
+        for name, mk, w, h, spp in (("large", r1.create_large_scene, 1200, 800, 10), ("medium", r1.create_medium_scene, 333, 211, 5)):
+            sc = mk(w, h)
+            m.set_scene(sc)
+            renderer.set_scene(sc)
+            p = r1.make_params(w, h, spp, 10001)
+            img, rays, secs = m.render(p)
+            ref, ref_rays, _ = renderer.render(p)
+            assert rays == ref_rays and img.tobytes() == ref.tobytes(), name
+            assert secs > 0
+            again = m.render(p)
+            assert again[1] == rays and again[0].tobytes() == img.tobytes()
+    finally:
+        m.close()
+    with pytest.raises(r1.R1Error) as e:   # an RCCL communicator needs distinct devices
+        binding.MultiRenderer([0, 0])
+    assert e.value.code == binding.R1_EINVAL
+
+
+def test_rayweek1_hip_gather_rccl_one_device(tmp_path):
+    """The drop-in program with --gather rccl (one-rank communicator here): same report block, same files,
+    same pixels and ray counts as the plain run."""
+    import re
+    import subprocess
+    import os
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rays1bench_amd", "lib", "rayweek1_hip")
+    args = ["-w", "--width", "160", "--height", "96", "--spp", "3"]
+    (tmp_path / "a").mkdir(), (tmp_path / "b").mkdir()
+    plain = subprocess.run([exe] + args, cwd=tmp_path / "a", capture_output=True, timeout=300)
+    rccl = subprocess.run([exe] + args + ["--devices", "1", "--gather", "rccl"], cwd=tmp_path / "b", capture_output=True, timeout=300)
+    assert plain.returncode == 0 and rccl.returncode == 0, rccl.stderr.decode()
+    assert "gather: RCCL" in rccl.stdout.decode()
+    assert re.findall(r"total rays:     (\d+)", plain.stdout.decode()) == re.findall(r"total rays:     (\d+)", rccl.stdout.decode())
+    for n in ("small", "medium", "large"):
+        assert open(tmp_path / "a" / f"out_{n}.tga", "rb").read() == open(tmp_path / "b" / f"out_{n}.tga", "rb").read()
+        assert re.fullmatch(r"hip\|\d+\.\d{3}s\|\d+\|\d+\.\d{3} mrays/s\|", open(tmp_path / "b" / f"out_{n}.txt").read())

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/rays1.h but not exported"
     assert declared == {s[0] for s in binding.SYMBOLS}
-    assert L.r1_abi_version() == 1
+    assert L.r1_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
