@@ -723,7 +723,10 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     // Latency mode: every wave of the full grid takes one wave-full of samples per atomic (what a wave
     // still holds when the queue runs dry is the frame's tail: with 256-sample chunks the waves found
     // the queue empty over a span of 0.7 ms), which one counter cannot serve: sub-queues.
-    if (!throughput_mode)
+    // (also for a throughput-mode frame that was given a large grid: what matters is how many waves share the queue)
+    static const long long lat_blocks_env = getenv("R1_LAT_BLOCKS") ? atoll(getenv("R1_LAT_BLOCKS")) : 100000000;
+    const bool latency_kernel = !throughput_mode || blocks >= lat_blocks_env;
+    if (latency_kernel)
     {
         static const int nq_env = getenv("R1_NQ") ? atoi(getenv("R1_NQ")) : 0, ch_env = getenv("R1_CHUNK") ? atoi(getenv("R1_CHUNK")) : 0;
         long long nq = nq_env > 0 ? nq_env : R1_SUBQUEUES;
@@ -766,7 +769,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     R1_HIP(hipMemsetAsync(d_rays, 0, 8, st));
     R1_HIP(hipEventRecord(e0, st));
     if (c->total_samples && variant != 6)
-        R1_HIP(r1_launch_trace(&a, variant, big, throughput_mode ? 0 : 1, (int)blocks, st));
+        R1_HIP(r1_launch_trace(&a, variant, big, latency_kernel ? 1 : 0, (int)blocks, st));
     if (c->total_samples && variant == 6)
     {
         // wavefront variant: path state, per-level queues and the attenuation stack live in HBM
