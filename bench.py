@@ -162,7 +162,9 @@ def measure_work(rend, p, info, binding):
                 "flop_per_launch": visits * 2 * FLOP_BOX + pairs * 2 * FLOP_SPHERE,
                 "lane_utilisation": {"at_hit_test": st["alive_lanes"] / (64.0 * it),
                                      "node_loop": visits / (64.0 * max(st["candidate_loop_trips"], 1)),
-                                     "leaf_loop": pairs / (64.0 * max(st["overflow_lanes"], 1))}}
+                                     # a leaf trip tests up to two sphere pairs per lane: this is pairs per (trip, lane) / 2,
+                                     # a lower bound of the fraction of lanes busy in the leaf steps
+                                     "leaf_loop": min(1.0, pairs / (2 * 64.0 * max(st["overflow_lanes"], 1)))}}
     groups = info["groups"]
     slots = st["candidate_loop_trips"] * 64  # member slots the cooperative exact phase walked
     return {"source": "R1_VARIANT_STATS frame (same samples as the timed kernel)", "rays_per_launch": rays,

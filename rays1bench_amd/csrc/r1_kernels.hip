@@ -588,6 +588,58 @@ __device__ __forceinline__ bool bvh_box(const float mx, const float my, const fl
     return tn <= fminf(tf, best) && tf >= 0.0f;
 }
 
+// Up to TWO sphere pairs (four spheres) of a leaf for this lane's ray: first pass 1 of Hitable::hit for all
+// four (rayweek1.cpp:192-202: nb, discr), then pass 2 (:294-313: square root, roots, strict compares) only
+// for the spheres whose discriminant has a clear sign bit (:204), one per trip of a wave-uniform loop.  A
+// lane rarely holds more than one such sphere in a leaf, so the wave runs the expensive half ~2 times per
+// four spheres instead of four times (it used to cost 155 VALU instructions per pair, two thirds of them
+// pass 2).  Same offers as exact_offer, same update rule (minimum offer, ties to the lowest sphere index).
+// `pairs` = 1 or 2; an odd sphere's partner has radius_sq = -inf (discriminant -inf: never flagged).
+__device__ __forceinline__ void leaf_quad(const float4 *__restrict__ prims, const uint32_t *__restrict__ ids, const uint32_t first,
+                                          const uint32_t pairs, const V3 o, const V3 d, float &best, uint32_t &best_id)
+{
+    const float4 a0 = prims[2 * (size_t)first], a1 = prims[2 * (size_t)first + 1];
+    float4 b0 = a0, b1 = a1;
+    if (pairs > 1u)
+        b0 = prims[2 * (size_t)first + 2], b1 = prims[2 * (size_t)first + 3];
+    float nb[4], ds[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+    {
+        const float4 p0 = q < 2 ? a0 : b0, p1 = q < 2 ? a1 : b1;
+        const float cx = (q & 1) ? p0.y : p0.x, cy = (q & 1) ? p0.w : p0.z, cz = (q & 1) ? p1.y : p1.x, rsq = (q & 1) ? p1.w : p1.z;
+        const float cox = cx - o.x, coy = cy - o.y, coz = cz - o.z;
+        nb[q] = __fmaf_rn(coz, d.z, __fmaf_rn(coy, d.y, cox * d.x));
+        const float c = __fmaf_rn(coz, coz, __fmaf_rn(coy, coy, cox * cox)) - rsq;
+        ds[q] = nb[q] * nb[q] - c;
+    }
+    uint32_t mask = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        mask |= (__float_as_uint(ds[q]) >> 31) ? 0u : (1u << q);
+    if (pairs < 2u)
+        mask &= 3u;
+    while (__ballot(mask != 0u)) // wave-uniform
+    {
+        if (mask)
+        {
+            const uint32_t q = (uint32_t)__ffs((int)mask) - 1u;
+            mask &= mask - 1u;
+            const float n_ = q == 0u ? nb[0] : (q == 1u ? nb[1] : (q == 2u ? nb[2] : nb[3]));
+            const float d_ = q == 0u ? ds[0] : (q == 1u ? ds[1] : (q == 2u ? ds[2] : ds[3]));
+            const float root = ieee_sqrt(d_);
+            const float t1 = n_ - root;
+            const float t = (t1 > 0.001f) ? t1 : n_ + root;
+            if (t > 0.001f && t < FLT_MAX && t <= best)
+            {
+                const uint32_t id = ids[2 * (size_t)first + q];
+                if (t < best || id < best_id)
+                    best = t, best_id = id;
+            }
+        }
+    }
+}
+
 // Traversal state of one lane.  It lives in registers ACROSS the outer loop of the trace kernel
 // (carry-over, below); the stack entries are in LDS, [entry][thread].
 struct Trav
@@ -681,26 +733,14 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
         {
             if (STATS)
             {
-                wstat[5] += 1;
+                wstat[5] += (((cur >> 28) & 7u) < 2u ? 1 : 2); // sphere pairs
                 if ((tid & 63) == __ffsll((long long)__ballot(1)) - 1)
                     wstat[3] += 1;
             }
-            const uint32_t first = cur & 0x0FFFFFFFu;
-            const float4 p0 = prims[2 * (size_t)first], p1 = prims[2 * (size_t)first + 1];
-#pragma unroll
-            for (uint32_t c = 0; c < 2u; ++c)
-            {
-                f4 e;
-                e.x = c ? p0.y : p0.x, e.y = c ? p0.w : p0.z, e.z = c ? p1.y : p1.x, e.w = c ? p1.w : p1.z;
-                const float t = exact_offer(e, o, d);
-                if (t <= best && t < FLT_MAX)
-                {
-                    const uint32_t id = ids[2 * (size_t)first + c];
-                    if (t < best || id < best_id)
-                        best = t, best_id = id;
-                }
-            }
-            cur = cur + 1u - 0x10000000u; // next pair, one fewer to go
+            const uint32_t first = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
+            const uint32_t take = cnt < 2u ? cnt : 2u; // up to four spheres per trip
+            leaf_quad(prims, ids, first, take, o, d, best, best_id);
+            cur = cur + take - (take << 28); // next pairs, `take` fewer to go
             if ((cur & 0x70000000u) == 0u)
                 cur = sp > 0 ? trav[--sp * R1_BLOCK + tid] : R1_BVH_DONE;
         }
@@ -743,28 +783,16 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
             // leaf: `cnt` PAIRS of spheres {cx_a cx_b cy_a cy_b} {cz_a cz_b rsq_a rsq_b}; an odd
             // sphere's partner has radius_sq = -inf (discriminant -inf: never offers a hit)
             const uint32_t first = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
-            for (uint32_t j = 0; j < cnt; ++j)
+            for (uint32_t j = 0; j < cnt; j += 2u)
             {
+                const uint32_t take = cnt - j < 2u ? 1u : 2u;
                 if (STATS)
                 {
-                    wstat[5] += 1;
+                    wstat[5] += take;
                     if ((tid & 63) == __ffsll((long long)__ballot(1)) - 1)
                         wstat[3] += 1;
                 }
-                const float4 p0 = prims[2 * (size_t)(first + j)], p1 = prims[2 * (size_t)(first + j) + 1];
-#pragma unroll
-                for (uint32_t c = 0; c < 2u; ++c)
-                {
-                    f4 e;
-                    e.x = c ? p0.y : p0.x, e.y = c ? p0.w : p0.z, e.z = c ? p1.y : p1.x, e.w = c ? p1.w : p1.z;
-                    const float t = exact_offer(e, o, d); // the reference's pass 1 + pass 2 for this sphere
-                    if (t <= best && t < FLT_MAX)
-                    {
-                        const uint32_t id = ids[2 * (size_t)(first + j) + c];
-                        if (t < best || id < best_id)
-                            best = t, best_id = id;
-                    }
-                }
+                leaf_quad(prims, ids, first + j, take, o, d, best, best_id);
             }
             cur = sp > 0 ? trav[--sp * R1_BLOCK + tid] : R1_BVH_DONE;
         }

@@ -34,7 +34,9 @@ out = {
     "node_loop_trips_per_iteration": st["candidate_loop_trips"] / it,
     "leaf_loop_trips_per_iteration": st["overflow_lanes"] / it,
     "node_loop_lane_utilisation": st["candidates"] / (64.0 * max(st["candidate_loop_trips"], 1)),
-    "leaf_loop_lane_utilisation": st["cycles_pass1"] / (64.0 * max(st["overflow_lanes"], 1)),
+    # a leaf trip tests up to TWO sphere pairs per lane (leaf_quad): lanes busy = pair tests / 2 at most
+    "leaf_loop_lane_utilisation": min(1.0, st["cycles_pass1"] / (2 * 64.0 * max(st["overflow_lanes"], 1))),
+    "sphere_pairs_per_leaf_trip_and_lane": st["cycles_pass1"] / (64.0 * max(st["overflow_lanes"], 1)),
     "share_refill": st["cycles_refill"] / st["cycles_wave"],
     "share_sweep": st["cycles_candidates"] / st["cycles_wave"],
     "share_shade": st["cycles_shade"] / st["cycles_wave"],
