@@ -155,16 +155,15 @@ def measure_work(rend, p, info, binding):
     st = rend.last_stats()
     it = max(st["wave_iterations"], 1)
     if info["kernel"] == 4:
-        visits, pairs = st["candidates"], st["cycles_pass1"]
+        # slot "cycles_pass1" of the tree build: sphere-pair tests (low 32 bits) | leaf trips summed over lanes << 32
+        visits, pairs, leaf_lane_trips = st["candidates"], st["cycles_pass1"] & 0xFFFFFFFF, st["cycles_pass1"] >> 32
         return {"source": "R1_VARIANT_BVH_STATS frame (same samples as the timed kernel)", "rays_per_launch": rays,
                 "node_visits_per_ray": visits / rays, "sphere_pair_tests_per_ray": pairs / rays,
                 "flop_per_node_visit": 2 * FLOP_BOX, "flop_per_sphere_pair_test": 2 * FLOP_SPHERE,
                 "flop_per_launch": visits * 2 * FLOP_BOX + pairs * 2 * FLOP_SPHERE,
                 "lane_utilisation": {"at_hit_test": st["alive_lanes"] / (64.0 * it),
                                      "node_loop": visits / (64.0 * max(st["candidate_loop_trips"], 1)),
-                                     # a leaf trip tests up to two sphere pairs per lane: this is pairs per (trip, lane) / 2,
-                                     # a lower bound of the fraction of lanes busy in the leaf steps
-                                     "leaf_loop": min(1.0, pairs / (2 * 64.0 * max(st["overflow_lanes"], 1)))}}
+                                     "leaf_loop": leaf_lane_trips / (64.0 * max(st["overflow_lanes"], 1))}}
     groups = info["groups"]
     slots = st["candidate_loop_trips"] * 64  # member slots the cooperative exact phase walked
     return {"source": "R1_VARIANT_STATS frame (same samples as the timed kernel)", "rays_per_launch": rays,

@@ -733,7 +733,7 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
         {
             if (STATS)
             {
-                wstat[5] += (((cur >> 28) & 7u) < 2u ? 1 : 2); // sphere pairs
+                wstat[5] += (((cur >> 28) & 7u) < 2u ? 1ull : 2ull) | (1ull << 32); // sphere pairs | leaf trips of this lane << 32
                 if ((tid & 63) == __ffsll((long long)__ballot(1)) - 1)
                     wstat[3] += 1;
             }
@@ -788,7 +788,7 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
                 const uint32_t take = cnt - j < 2u ? 1u : 2u;
                 if (STATS)
                 {
-                    wstat[5] += take;
+                    wstat[5] += (unsigned long long)take | (1ull << 32);
                     if ((tid & 63) == __ffsll((long long)__ballot(1)) - 1)
                         wstat[3] += 1;
                 }

@@ -23,6 +23,8 @@ for v in (binding.VARIANT_BVH, binding.VARIANT_BVH_STATS):
         img, rays, secs = rend.render(r1.make_params(w, h, spp, 10001, variant=v))
     print(f"variant {v}: rays {rays} device {rend.last_timing()[1]:.3f} ms")
 st = rend.last_stats()
+leaf_lane_trips = st["cycles_pass1"] >> 32          # slot [5]: sphere-pair tests (low 32 bits) | leaf trips summed over lanes << 32
+st["cycles_pass1"] &= 0xFFFFFFFF
 info = rend.launch_info()
 waves = info["blocks"] * 4
 it = st["wave_iterations"]
@@ -34,9 +36,8 @@ out = {
     "node_loop_trips_per_iteration": st["candidate_loop_trips"] / it,
     "leaf_loop_trips_per_iteration": st["overflow_lanes"] / it,
     "node_loop_lane_utilisation": st["candidates"] / (64.0 * max(st["candidate_loop_trips"], 1)),
-    # a leaf trip tests up to TWO sphere pairs per lane (leaf_quad): lanes busy = pair tests / 2 at most
-    "leaf_loop_lane_utilisation": min(1.0, st["cycles_pass1"] / (2 * 64.0 * max(st["overflow_lanes"], 1))),
-    "sphere_pairs_per_leaf_trip_and_lane": st["cycles_pass1"] / (64.0 * max(st["overflow_lanes"], 1)),
+    "leaf_loop_lane_utilisation": leaf_lane_trips / (64.0 * max(st["overflow_lanes"], 1)),  # lanes on a leaf per leaf trip / 64
+    "sphere_pairs_per_leaf_visit": st["cycles_pass1"] / max(leaf_lane_trips, 1),
     "share_refill": st["cycles_refill"] / st["cycles_wave"],
     "share_sweep": st["cycles_candidates"] / st["cycles_wave"],
     "share_shade": st["cycles_shade"] / st["cycles_wave"],
