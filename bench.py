@@ -193,6 +193,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--check", action="store_true",
                     help="after the timed region compare the gathered + assembled image and ray count with an unsharded render")
+    ap.add_argument("--pixel-mode", action="store_true",
+                    help="r1_set_pixel_mode: lanes own pixels, 3 B/pixel written, no per-sample workspace, no resolve launch (~10 %% slower)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-table", action="store_true",
                     help="also time the reference's step13 (all threads / 1 thread) on the three scenes and the step1 port "
@@ -252,6 +254,8 @@ def main():
             gw, gh = (int(v) for v in args.grid.split("x")) if args.scene == "grid" else (0, 0)
             self.scene = r1.Scene(SCENE_KIND[args.scene], w, h, gw, gh)
             self.rend.set_scene(self.scene)
+            if args.pixel_mode:
+                self.rend.set_pixel_mode(True)
             self.record = torch.zeros(record_bytes, dtype=torch.uint8, device=dev)
             self.gathered = torch.zeros(shards * record_bytes, dtype=torch.uint8, device=dev) if shards > 1 else self.record
             self.image = torch.zeros((h, w, 3), dtype=torch.uint8, device=dev)

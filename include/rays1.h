@@ -181,6 +181,15 @@ size_t r1_shard_block_bytes(const r1_params *params);
  * flight (one context + stream per frame in flight). */
 int r1_render_shard_device(r1_context *ctx, const r1_params *params, void *d_block, void *d_num_rays, void *hip_stream);
 
+/* PIXEL mode for r1_render_shard_device (off by default).  On: a lane of the trace kernel owns a pixel and runs
+ * its spp samples one after the other, so the `col += color()` of rayweek1.cpp:762 happens in a register in the
+ * reference's order and the resolved pixel (rayweek1.cpp:765-775) is all the frame writes — 3 bytes per pixel
+ * instead of 16 bytes per sample, no resolve launch, no per-sample workspace (3.9 GB per frame in flight at
+ * 1200x800x250).  Same pixels and ray counts; measured ~10 % slower on the reference's scenes (a frame's last
+ * pixels are ten dependent samples long), which is why it is a choice.  The host-returning entry points and
+ * r1_render_samples always keep per-sample records. */
+int r1_set_pixel_mode(r1_context *ctx, int32_t on);
+
 /* Same outputs, sized for latency instead: ONE frame whose result the caller waits for (the full
  * persistent grid and the latency-mode kernels of r1_render).  Used by r1_multi_render. */
 int r1_render_shard_device_once(r1_context *ctx, const r1_params *params, void *d_block, void *d_num_rays, void *hip_stream);

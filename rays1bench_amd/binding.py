@@ -87,6 +87,7 @@ SYMBOLS = [
     ("r1_tile_count", C.c_int, [C.POINTER(Params), _i32p, _i32p]),
     ("r1_shard_block_bytes", C.c_size_t, [C.POINTER(Params)]),
     ("r1_render_shard_device", C.c_int, [_ctx, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("r1_set_pixel_mode", C.c_int, [_ctx, C.c_int32]),
     ("r1_render_shard_device_once", C.c_int, [_ctx, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p]),
     ("r1_multi_create", C.c_int, [C.c_int32, _i32p, C.POINTER(C.c_void_p)]),
     ("r1_multi_destroy", None, [C.c_void_p]),
@@ -239,6 +240,9 @@ class Renderer:
     def assemble_device_strided(self, params, d_blocks_ptr, shard_stride_bytes, d_rgb_ptr, stream_ptr=None):
         _check(lib().r1_assemble_device_strided(self._c, C.byref(params), C.c_void_p(d_blocks_ptr), shard_stride_bytes,
                                                 C.c_void_p(d_rgb_ptr), C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def set_pixel_mode(self, on):
+        _check(lib().r1_set_pixel_mode(self._c, 1 if on else 0))
 
     def sync(self):
         _check(lib().r1_sync(self._c))

@@ -21,12 +21,13 @@
 #include "../../include/rays1.h"
 #include "r1_device.h"
 
-extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int big, int latency, int blocks, hipStream_t stream);
+extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int big, int mode, int blocks, hipStream_t stream);
+extern "C" int r1_trace_mode(int variant, int big, int wanted); // 0 samples + one queue, 1 latency, 2 pixel: what is built for (variant, big)
 extern "C" hipError_t r1_launch_resolve(const R1ResolveArgs *args, hipStream_t stream);
 extern "C" hipError_t r1_launch_wavefront(R1WaveArgs *w, int blocks, hipStream_t stream);
 extern "C" hipError_t r1_launch_assemble(const void *blocks, void *rgb, int width, int height, int tile_w, int tile_h, int tiles_x,
                                          int tiles_total, int num_shards, int tiles_per_shard, size_t shard_stride, hipStream_t stream);
-extern "C" hipError_t r1_trace_occupancy(int variant, int big, size_t dyn_lds, int *blocks_per_cu);
+extern "C" hipError_t r1_trace_occupancy(int variant, int big, int mode, size_t dyn_lds, int *blocks_per_cu);
 extern "C" int r1_params_check(const r1_params *p); // r1_host.cpp
 
 // r1_bvh.cpp
@@ -115,7 +116,8 @@ struct r1_context
     bool tile_key_valid = false;
     uint32_t n_local_tiles = 0, total_samples = 0, full = 0;
 
-    int occupancy[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // [variant + 8*big]
+    int occupancy[48] = {0}; // [variant + 8 * big + 16 * mode]
+    bool pixel_mode = false; // r1_set_pixel_mode
     DevBuf gstack; // blocks per CU of the trace kernel, by variant
 
     r1_launch_info info;
@@ -625,7 +627,13 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
         return rc;
     if ((rc = ensure(c->counters, R1_COUNTER_BYTES)))
         return rc;
-    if ((rc = ensure(c->samples, (size_t)(c->total_samples ? c->total_samples : 1) * 16)))
+    // kernel mode: the host-returning entry points run in latency mode, the throughput entry point with few long-lived
+    // waves per frame — per-sample records + r1_resolve_kernel either way, unless r1_set_pixel_mode chose PIXEL mode
+    // for the throughput entry point (a lane owns a pixel: no sample records, no resolve launch, ~10 % slower)
+    const int big_scene_ = c->n_active > R1_MAX_ACTIVE_10BIT ? 1 : 0;
+    const int mode = variant == 6 ? 0 : r1_trace_mode(variant, big_scene_, throughput_mode ? (c->pixel_mode ? 2 : 0) : 1);
+    const bool pixel_mode = mode == 2;
+    if (!pixel_mode && (rc = ensure(c->samples, (size_t)(c->total_samples ? c->total_samples : 1) * 16)))
         return rc;
 
     R1TraceArgs a;
@@ -671,10 +679,11 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     // workgroups per CU): 15 % slower.
     const int big = c->n_active > R1_MAX_ACTIVE_10BIT ? 1 : 0;
     a.bvh_depth = c->bvh_depth > 0 ? c->bvh_depth : 1;
-    if (c->occupancy[variant + 8 * big] == 0)
-        R1_HIP(r1_trace_occupancy(variant, big, (variant == 4 || variant == 5) ? (size_t)a.bvh_depth * R1_BLOCK * 4 : 0,
-                                  &c->occupancy[variant + 8 * big]));
-    int per_cu = c->occupancy[variant + 8 * big];
+    const int occ_slot = variant + 8 * big + 16 * mode;
+    if (c->occupancy[occ_slot] == 0)
+        R1_HIP(r1_trace_occupancy(variant, big, mode, (variant == 4 || variant == 5) ? (size_t)a.bvh_depth * R1_BLOCK * 4 : 0,
+                                  &c->occupancy[occ_slot]));
+    int per_cu = c->occupancy[occ_slot];
     if (per_cu < 1)
         per_cu = 1;
     if (per_cu > 8)
@@ -723,10 +732,23 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     // Latency mode: every wave of the full grid takes one wave-full of samples per atomic (what a wave
     // still holds when the queue runs dry is the frame's tail: with 256-sample chunks the waves found
     // the queue empty over a span of 0.7 ms), which one counter cannot serve: sub-queues.
-    // (also for a throughput-mode frame that was given a large grid: what matters is how many waves share the queue)
-    static const long long lat_blocks_env = getenv("R1_LAT_BLOCKS") ? atoll(getenv("R1_LAT_BLOCKS")) : 100000000;
-    const bool latency_kernel = !throughput_mode || blocks >= lat_blocks_env;
-    if (latency_kernel)
+    if (pixel_mode)
+    {
+        // the queue holds the padded pixels of the shard's tiles; chunks in pixels (a wave holds 64 pixels at a time)
+        const uint32_t tp = (uint32_t)(p->tile_w * p->tile_h);
+        a.full = tp;
+        a.div_full = make_div(tp);
+        a.total_samples = c->n_local_tiles * tp;
+        a.samples = (float4 *)d_out;
+        a.block_layout = block_layout;
+        a.inv_spp = (float)(1.0f / p->spp); // rayweek1.cpp:765
+        const long long waves = blocks * (R1_BLOCK / 64);
+        long long cm = (long long)a.total_samples / (waves * 12);
+        cm = cm < 16 ? 16 : (cm > 128 ? 128 : cm);
+        a.chunk_max = (uint32_t)cm;
+        a.chunk_min = 8;
+    }
+    if (mode == 1)
     {
         static const int nq_env = getenv("R1_NQ") ? atoi(getenv("R1_NQ")) : 0, ch_env = getenv("R1_CHUNK") ? atoi(getenv("R1_CHUNK")) : 0;
         long long nq = nq_env > 0 ? nq_env : R1_SUBQUEUES;
@@ -769,7 +791,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     R1_HIP(hipMemsetAsync(d_rays, 0, 8, st));
     R1_HIP(hipEventRecord(e0, st));
     if (c->total_samples && variant != 6)
-        R1_HIP(r1_launch_trace(&a, variant, big, latency_kernel ? 1 : 0, (int)blocks, st));
+        R1_HIP(r1_launch_trace(&a, variant, big, mode, (int)blocks, st));
     if (c->total_samples && variant == 6)
     {
         // wavefront variant: path state, per-level queues and the attenuation stack live in HBM
@@ -812,7 +834,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     r.inv_spp = (float)(1.0f / p->spp); // rayweek1.cpp:765
     r.out = (uint8_t *)d_out;
     r.block_layout = block_layout;
-    if (c->n_local_tiles)
+    if (c->n_local_tiles && !pixel_mode)
         R1_HIP(r1_launch_resolve(&r, st));
     R1_HIP(hipEventRecord(e2, st));
     c->last0 = e0, c->last1 = e1, c->last2 = e2;
@@ -986,6 +1008,14 @@ extern "C" int r1_assemble_device_strided(r1_context *c, const r1_params *p, con
 extern "C" int r1_assemble_device(r1_context *c, const r1_params *p, const void *d_blocks, void *d_rgb, void *hip_stream)
 {
     return r1_assemble_device_strided(c, p, d_blocks, 0, d_rgb, hip_stream);
+}
+
+extern "C" int r1_set_pixel_mode(r1_context *c, int32_t on)
+{
+    if (!c)
+        return R1_EINVAL;
+    c->pixel_mode = on != 0;
+    return R1_OK;
 }
 
 extern "C" int r1_sync(r1_context *c)

@@ -98,11 +98,15 @@ struct R1TraceArgs
                                  // chunk_max slots, chunk c belongs to sub-queue c % nq and a wave only pulls from sub-queue wave % nq:
                                  // a returning atomic on ONE line sustains 88 M/s on this chip (tools/ubench_atomic.hip), too few for
                                  // 6144 waves taking a wave-full at a time
-    float4 *samples;             // [total_samples] {r, g, b, bit_cast<float>(rays)}
+    float4 *samples;             // [total_samples] {r, g, b, bit_cast<float>(rays)}.  PIXEL mode (r1_kernels.hip struct Pixel): the
+                                 // queue holds PIXELS (full = tile_w * tile_h, total_samples = padded pixels of the shard) and this
+                                 // is the uint8 RGB output the kernel resolves into
     unsigned long long *num_rays; // accumulated color() invocations
     uint32_t *gstack;             // big scenes: attenuation stack [R1_STACK_ENTRIES][grid threads], else null
     unsigned long long *stats;    // diagnostic counters (R1_VARIANT_STATS builds only), else null
     int32_t bvh_depth;            // tree kernels: traversal stack entries per thread (dynamic LDS = depth * R1_BLOCK * 4)
+    int32_t block_layout;         // PIXEL mode: 1 = `samples` is a dense tile block (pixel index = queue slot), 0 = a row-major image
+    float inv_spp;                // PIXEL mode: (float)(1.0f / spp), rayweek1.cpp:765
     uint32_t coop_lanes;          // small scenes: once the queue is empty, a wave with <= coop_lanes live paths tests each of them
                                   // against ALL spheres, 64 at a time across the wave (cooperative_sweep), instead of walking the tree
                                   // with 60 lanes masked off: the frame's tail is a few 51-bounce chains, and this shortens a step

@@ -893,32 +893,14 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t n, const R1FastDiv dv)
     return dv.pow2 ? (n >> dv.shift) : (__umulhi(n, dv.mul) >> dv.shift);
 }
 
-// slot k -> (tile, pixel, sample); then seeds + primary ray (rayweek1.cpp:759-760).
-// Returns false for a void slot (pixel of an edge tile that lies outside the image).
-__device__ __forceinline__ bool start_sample(const R1TraceArgs &A, Path &p, uint32_t k)
+// seeds + primary ray of sample s of pixel (x, y) (rayweek1.cpp:759-760)
+__device__ __forceinline__ void start_ray(const R1TraceArgs &A, Path &p, const int x, const int y, const uint32_t s)
 {
-    const uint32_t j = fastdiv(k, A.div_full);
-    const uint32_t r = k - j * A.full;
-    const uint32_t pix = fastdiv(r, A.div_spp);
-    const uint32_t s = r - pix * (uint32_t)A.spp;
-    const uint32_t ly = fastdiv(pix, A.div_tw);
-    const uint32_t lx = pix - ly * (uint32_t)A.tile_w;
-    const uint32_t tile = (uint32_t)A.shard + j * (uint32_t)A.num_shards;
-    const uint32_t ty = fastdiv(tile, A.div_tx);
-    const uint32_t tx = tile - ty * (uint32_t)A.tiles_x;
-    const int x = (int)(tx * (uint32_t)A.tile_w + lx);
-    const int y = (int)(ty * (uint32_t)A.tile_h + ly);
-    if (x >= A.width || y >= A.height)
-        return false;
-
     const r1_sample_seed sd = r1_seed_sample(A.seed, (uint32_t)(y * A.width + x), s);
     p.s_scalar = sd.scalar;
     p.s0 = sd.lane0;
     p.s1 = sd.lane1;
     p.s2 = sd.lane2;
-    // output slot: samples are stored [tile][sample][pixel] so that the resolve pass reads
-    // coalesced (consecutive pixels of one sample index)
-    p.k = (j * (uint32_t)A.spp + s) * (uint32_t)(A.tile_w * A.tile_h) + pix;
     p.rays = 0;
     p.depth = 0;
     p.sp = 0;
@@ -946,7 +928,71 @@ __device__ __forceinline__ bool start_sample(const R1TraceArgs &A, Path &p, uint
     const V3 dir =
         vsub(vsub(vadd(vadd(ld3(A.cam.lower_left), vscale(ld3(A.cam.horizontal), u)), vscale(ld3(A.cam.vertical), v)), org), offset);
     p.d = vunit(dir);
+}
+
+// (local tile j, pixel `pix` of the padded tile) -> image coordinates; false outside the image (edge tiles)
+__device__ __forceinline__ bool tile_pixel(const R1TraceArgs &A, const uint32_t j, const uint32_t pix, int &x, int &y)
+{
+    const uint32_t ly = fastdiv(pix, A.div_tw);
+    const uint32_t lx = pix - ly * (uint32_t)A.tile_w;
+    const uint32_t tile = (uint32_t)A.shard + j * (uint32_t)A.num_shards;
+    const uint32_t ty = fastdiv(tile, A.div_tx);
+    const uint32_t tx = tile - ty * (uint32_t)A.tiles_x;
+    x = (int)(tx * (uint32_t)A.tile_w + lx);
+    y = (int)(ty * (uint32_t)A.tile_h + ly);
+    return x < A.width && y < A.height;
+}
+
+// sample slot k -> (tile, pixel, sample); then seeds + primary ray.
+// Returns false for a void slot (pixel of an edge tile that lies outside the image).
+__device__ __forceinline__ bool start_sample(const R1TraceArgs &A, Path &p, uint32_t k)
+{
+    const uint32_t j = fastdiv(k, A.div_full);
+    const uint32_t r = k - j * A.full;
+    const uint32_t pix = fastdiv(r, A.div_spp);
+    const uint32_t s = r - pix * (uint32_t)A.spp;
+    int x, y;
+    if (!tile_pixel(A, j, pix, x, y))
+        return false;
+    // output slot: samples are stored [tile][sample][pixel] so that the resolve pass reads
+    // coalesced (consecutive pixels of one sample index)
+    p.k = (j * (uint32_t)A.spp + s) * (uint32_t)(A.tile_w * A.tile_h) + pix;
+    start_ray(A, p, x, y, s);
     return true;
+}
+
+// PIXEL mode (frames in flight): a lane owns a PIXEL and runs its spp samples one after the other, so
+// `col += color(...)` (rayweek1.cpp:762) happens in a register in the reference's order and the resolved
+// pixel (rayweek1.cpp:765-775) is the only thing the frame writes: no per-sample records, no second kernel.
+struct Pixel
+{
+    V3 acc;       // col of render_tile
+    uint32_t xy;  // x | y << 16
+    uint32_t off; // output pixel index (dense tile block: the queue slot itself; row-major image: y * width + x)
+    uint32_t s;   // next sample; == spp: no pixel in hand
+};
+
+// pixel slot kp of the frame's queue = (local tile, pixel of the padded tile) -> Pixel; false for a void slot
+__device__ __forceinline__ bool pixel_take(const R1TraceArgs &A, Pixel &px, const uint32_t kp)
+{
+    const uint32_t j = fastdiv(kp, A.div_full); // PIXEL mode: `full` = tile_w * tile_h
+    int x, y;
+    if (!tile_pixel(A, j, kp - j * A.full, x, y))
+        return false;
+    px.acc = mk(0, 0, 0);
+    px.xy = (uint32_t)x | ((uint32_t)y << 16);
+    px.off = A.block_layout ? kp : (uint32_t)(y * A.width + x);
+    px.s = 0;
+    return true;
+}
+
+// rayweek1.cpp:765-775: col *= 1 / spp; sqrtf per channel; (uint8)(int)(c * 255.99f)
+__device__ __forceinline__ void pixel_write(const R1TraceArgs &A, const Pixel &px)
+{
+    uint8_t *o = (uint8_t *)A.samples + 3 * (size_t)px.off; // PIXEL mode: `samples` is the output image / tile block
+    o[0] = (uint8_t)(int)(ieee_sqrt(px.acc.x * A.inv_spp) * 255.99f);
+    o[1] = (uint8_t)(int)(ieee_sqrt(px.acc.y * A.inv_spp) * 255.99f);
+    o[2] = (uint8_t)(int)(ieee_sqrt(px.acc.z * A.inv_spp) * 255.99f);
 }
 
 // Path state in memory, [3][n] float4: {ox oy oz dx} {dy dz s_scalar s0} {s1 s2 k rays|depth<<8|sp<<16}
@@ -1125,12 +1171,15 @@ struct TraceWaves
     static constexpr int value = STATS ? 1 : (VARIANT == 4 ? (BIG ? 1 : 6) : (VARIANT == 2 && !BIG ? 5 : 1));
 };
 
-// LAT = latency-mode build (the synchronous entry points: one frame, full grid): sub-queues and
+// MODE 1 = LAT = latency-mode build (the synchronous entry points: one frame, full grid): sub-queues and
 // the cooperative tail are compiled in.  The throughput-mode build (frames in flight, few
 // long-lived waves per frame) leaves them out: they cost it registers and bring it nothing.
-template <int VARIANT, bool STATS, bool BIG, bool LAT>
+// MODE 0 = frames in flight (the throughput entry point): samples in one guided queue, few long-lived waves per frame.
+// MODE 2 = PIXEL mode (the throughput entry point after r1_set_pixel_mode; see struct Pixel): the queue holds pixels.
+template <int VARIANT, bool STATS, bool BIG, int MODE>
 __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::value)) r1_trace_kernel(const R1TraceArgs A)
 {
+    constexpr bool LAT = MODE == 1, PIX = MODE == 2;
     typedef typename IdxType<BIG>::type IDX;
     unsigned long long wstat[16];
     if (STATS)
@@ -1165,6 +1214,8 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
     p.s_scalar = p.s0 = p.s1 = p.s2 = 1;
     p.k = 0, p.rays = 0, p.depth = 0, p.sp = 0;
     bool alive = false;
+    Pixel px; // PIXEL mode: the pixel this lane owns
+    px.acc = mk(0, 0, 0), px.xy = 0, px.off = 0, px.s = (uint32_t)A.spp;
     Trav tv; // tree kernels: this lane's walk (carried over outer iterations, see bvh_advance)
     trav_start(tv);
     tv.cur = R1_BVH_DONE;
@@ -1188,6 +1239,14 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
         // ---- refill finished lanes from the wave's chunk of the global sample queue ----
         if (STATS)
             wstat[15] = __builtin_readcyclecounter();
+        if (PIX && !alive && px.s < (uint32_t)A.spp)
+        {
+            // the next sample of the pixel in hand: no queue, no index arithmetic
+            start_ray(A, p, (int)(px.xy & 0xFFFFu), (int)(px.xy >> 16), px.s);
+            alive = true;
+            if (VARIANT == 4)
+                trav_start(tv);
+        }
         unsigned long long need = __ballot(!alive);
         while (need)
         {
@@ -1233,7 +1292,14 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
             // between frames than the refill saves.)
             if (!alive && rank < avail)
             {
-                alive = start_sample(A, p, q_next + rank); // false: void slot, ask again
+                if (PIX)
+                {
+                    alive = pixel_take(A, px, q_next + rank); // false: void slot, ask again
+                    if (alive)
+                        start_ray(A, p, (int)(px.xy & 0xFFFFu), (int)(px.xy >> 16), 0u);
+                }
+                else
+                    alive = start_sample(A, p, q_next + rank); // false: void slot, ask again
                 if (VARIANT == 4 && alive)
                     trav_start(tv);
             }
@@ -1307,7 +1373,14 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
             V3 col;
             if (shade_level<BIG>(A, p, hit, t_hit, s_stack, gstride, gtid, tid, col))
             {
-                A.samples[p.k] = make_float4(col.x, col.y, col.z, __uint_as_float(p.rays));
+                if (PIX)
+                {
+                    px.acc = vadd(px.acc, col); // col += color(...), samples in order (rayweek1.cpp:762)
+                    if (++px.s == (uint32_t)A.spp)
+                        pixel_write(A, px);
+                }
+                else
+                    A.samples[p.k] = make_float4(col.x, col.y, col.z, __uint_as_float(p.rays));
                 lane_rays += p.rays;
                 alive = false;
             }
@@ -1536,35 +1609,67 @@ __global__ void __launch_bounds__(256)
 
 // ---- launchers (called from r1_capi.cpp) -----------------------------------------------------
 
-extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int big_in, int latency, int blocks, hipStream_t stream)
+// The kernel mode that is built for (variant, big) given what the caller would like (0 samples + one guided queue,
+// 1 latency, 2 pixel): the reference-form sweep only exists in mode 0, the diagnostic builds follow the latency
+// mode, big scenes have no latency mode.
+extern "C" int r1_trace_mode(int variant, int big, int wanted)
+{
+    if (variant == 1)
+        return 0;
+    if (variant == 3 || variant == 5)
+        return big ? 0 : 1;
+    if (wanted == 1)
+        return big ? 0 : 1;
+    return wanted == 2 ? 2 : 0;
+}
+
+extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int big_in, int mode, int blocks, hipStream_t stream)
 {
     // dynamic LDS: the traversal stack of the tree kernels, one entry per inner node on a path
     const size_t trav = (variant == 4 || variant == 5) ? (size_t)args->bvh_depth * R1_BLOCK * sizeof(uint32_t) : 0;
     const bool big = big_in != 0; // 32-bit hit indices, attenuation stack in the global workspace
-    const bool lat = latency != 0 && !big;
-#define R1_GO(V, S, B, L) hipLaunchKernelGGL((r1_trace_kernel<V, S, B, L>), dim3(blocks), dim3(R1_BLOCK), (V) == 4 ? trav : 0, stream, *args)
+#define R1_GO(V, S, B, M) hipLaunchKernelGGL((r1_trace_kernel<V, S, B, M>), dim3(blocks), dim3(R1_BLOCK), (V) == 4 ? trav : 0, stream, *args)
+    if (mode != r1_trace_mode(variant, big_in, mode))
+        return hipErrorInvalidValue; // the caller sizes its arguments by the mode: it must be the one that is built
     if (variant == 5 && big)
-        R1_GO(4, true, true, false);
+        R1_GO(4, true, true, 0);
     else if (variant == 5)
-        R1_GO(4, true, false, true); // the diagnostic build follows the latency-mode kernel (it is only run synchronously)
+        R1_GO(4, true, false, 1); // the diagnostic builds follow the latency-mode kernels (they are only run synchronously)
     else if (variant == 4 && big)
-        R1_GO(4, false, true, false);
-    else if (variant == 4 && lat)
-        R1_GO(4, false, false, true);
+    {
+        if (mode == 2)
+            R1_GO(4, false, true, 2);
+        else
+            R1_GO(4, false, true, 0);
+    }
     else if (variant == 4)
-        R1_GO(4, false, false, false);
+    {
+        if (mode == 2)
+            R1_GO(4, false, false, 2);
+        else if (mode == 1)
+            R1_GO(4, false, false, 1);
+        else
+            R1_GO(4, false, false, 0);
+    }
     else if (variant == 1 && big)
-        R1_GO(1, false, true, false);
+        R1_GO(1, false, true, 0);
     else if (variant == 1)
-        R1_GO(1, false, false, false);
+        R1_GO(1, false, false, 0);
     else if (variant == 3 && !big)
-        R1_GO(2, true, false, true);
+        R1_GO(2, true, false, 1);
     else if (big)
-        R1_GO(2, false, true, false);
-    else if (lat)
-        R1_GO(2, false, false, true);
+    {
+        if (mode == 2)
+            R1_GO(2, false, true, 2);
+        else
+            R1_GO(2, false, true, 0);
+    }
+    else if (mode == 2)
+        R1_GO(2, false, false, 2);
+    else if (mode == 1)
+        R1_GO(2, false, false, 1);
     else
-        R1_GO(2, false, false, false);
+        R1_GO(2, false, false, 0);
 #undef R1_GO
     return hipGetLastError();
 }
@@ -1604,25 +1709,25 @@ extern "C" hipError_t r1_launch_assemble(const void *blocks, void *rgb, int widt
     return hipGetLastError();
 }
 
-extern "C" hipError_t r1_trace_occupancy(int variant, int big, size_t dyn_lds, int *blocks_per_cu)
+extern "C" hipError_t r1_trace_occupancy(int variant, int big, int mode, size_t dyn_lds, int *blocks_per_cu)
 {
-#define R1_OCC(V, S, B, L) hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<V, S, B, L>, R1_BLOCK, (V) == 4 ? dyn_lds : 0)
+#define R1_OCC(V, S, B, M) hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<V, S, B, M>, R1_BLOCK, (V) == 4 ? dyn_lds : 0)
     if (variant == 5 && big)
-        return R1_OCC(4, true, true, false);
+        return R1_OCC(4, true, true, 0);
     if (variant == 5)
-        return R1_OCC(4, true, false, true);
+        return R1_OCC(4, true, false, 1);
     if (variant == 4 && big)
-        return R1_OCC(4, false, true, false);
+        return mode == 2 ? R1_OCC(4, false, true, 2) : R1_OCC(4, false, true, 0);
     if (variant == 4)
-        return R1_OCC(4, false, false, true);
+        return mode == 2 ? R1_OCC(4, false, false, 2) : (mode == 1 ? R1_OCC(4, false, false, 1) : R1_OCC(4, false, false, 0));
     if (variant == 1 && big)
-        return R1_OCC(1, false, true, false);
+        return R1_OCC(1, false, true, 0);
     if (variant == 1)
-        return R1_OCC(1, false, false, false);
+        return R1_OCC(1, false, false, 0);
     if (variant == 3 && !big)
-        return R1_OCC(2, true, false, true);
+        return R1_OCC(2, true, false, 1);
     if (big)
-        return R1_OCC(2, false, true, false);
-    return R1_OCC(2, false, false, true);
+        return mode == 2 ? R1_OCC(2, false, true, 2) : R1_OCC(2, false, true, 0);
+    return mode == 2 ? R1_OCC(2, false, false, 2) : (mode == 1 ? R1_OCC(2, false, false, 1) : R1_OCC(2, false, false, 0));
 #undef R1_OCC
 }

@@ -373,3 +373,48 @@ def test_rayweek1_hip_gather_rccl_one_device(tmp_path):
     for n in ("small", "medium", "large"):
         assert open(tmp_path / "a" / f"out_{n}.tga", "rb").read() == open(tmp_path / "b" / f"out_{n}.tga", "rb").read()
         assert re.fullmatch(r"hip\|\d+\.\d{3}s\|\d+\|\d+\.\d{3} mrays/s\|", open(tmp_path / "b" / f"out_{n}.txt").read())
+
+
+# ---- PIXEL mode of the throughput entry point (r1_set_pixel_mode) --------------------------------------
+
+
+@pytest.mark.parametrize("case", ["large_1200x800x10_8shards", "medium_ragged_tiles", "large_96x64x250", "grid_1600_spheres", "sweep_kernel"])
+def test_pixel_mode_writes_the_same_pixels_and_counts(case):
+    """r1_set_pixel_mode: lanes own pixels and resolve in-kernel (3 B/pixel, no per-sample records, no resolve
+    launch).  The device-resident shard blocks must equal, byte for byte, what the per-sample path renders."""
+    torch = pytest.importorskip("torch")
+    from rays1bench_amd import sharding
+    variant = binding.VARIANT_DEFAULT
+    if case == "large_1200x800x10_8shards":
+        sc, w, h, spp, shards, tw, th = r1.create_large_scene(1200, 800), 1200, 800, 10, 8, 32, 32
+    elif case == "medium_ragged_tiles":
+        sc, w, h, spp, shards, tw, th = r1.create_medium_scene(150, 90), 150, 90, 3, 3, 24, 40
+    elif case == "large_96x64x250":
+        sc, w, h, spp, shards, tw, th = r1.create_large_scene(96, 64), 96, 64, 250, 2, 32, 32
+    elif case == "grid_1600_spheres":
+        sc, w, h, spp, shards, tw, th = r1.create_grid_scene(160, 120, 50, 32), 160, 120, 4, 2, 32, 32
+    else:
+        sc, w, h, spp, shards, tw, th, variant = r1.create_large_scene(320, 200), 320, 200, 6, 1, 32, 32, binding.VARIANT_PREFILTER
+    rend = r1.Renderer(0)
+    try:
+        rend.set_scene(sc)
+        ref, ref_rays, _ = rend.render(r1.make_params(w, h, spp, 77, tile_w=tw, tile_h=th, variant=variant))
+        rend.set_pixel_mode(True)
+        nbytes = binding.shard_block_bytes(r1.make_params(w, h, spp, 77, tile_w=tw, tile_h=th, shard=0, num_shards=shards))
+        rec = nbytes + sharding.RECORD_TRAILER
+        records = torch.zeros((shards, rec), dtype=torch.uint8, device="cuda")
+        out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        for s in range(shards):
+            rend.render_shard_device(r1.make_params(w, h, spp, 77, tile_w=tw, tile_h=th, shard=s, num_shards=shards, variant=variant),
+                                     records[s].data_ptr(), records[s].data_ptr() + nbytes, stream)
+        rend.assemble_device_strided(r1.make_params(w, h, spp, 77, tile_w=tw, tile_h=th, shard=0, num_shards=shards), records.data_ptr(), rec,
+                                     out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert sharding.total_rays(records.view(-1), shards) == ref_rays
+        assert out.cpu().numpy().tobytes() == ref.tobytes()
+        # and the host-returning entry point of the same context still renders per sample
+        again, rays2, samples = rend.render_samples(r1.make_params(w, h, spp, 77, tile_w=tw, tile_h=th, variant=variant))
+        assert rays2 == ref_rays and again.tobytes() == ref.tobytes() and int(rays_of(samples).sum()) == ref_rays
+    finally:
+        rend.close()

@@ -1,12 +1,10 @@
 #!/bin/bash
-# tools/lib_ab.sh TAG... — throughput / synchronous / config-5 rates of several builds of librays1.so (rays1bench_amd/lib/librays1_TAG.so.bak)
+# tools/lib_ab.sh TAG... — throughput / synchronous rates of several builds of librays1.so (rays1bench_amd/lib/librays1_TAG.so.bak)
 R=$GRAFT_REPO_ROOT; cd $R
 cp rays1bench_amd/lib/librays1.so /tmp/keep.so
 for rep in 1 2; do for tag in "$@"; do
   cp rays1bench_amd/lib/librays1_$tag.so.bak rays1bench_amd/lib/librays1.so
   echo -n "$tag: "
-  python bench.py --no-cpu-baseline --steps 300 --warmup 20 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('inflight %.0f mrays/s (%.4f ms)  sync device %.4f ms  sweep %.0f' % (d['value'], d['ms_per_step'], d['value_dispatch_to_host']['device_ms_per_step'], d['exhaustive_sweep']['value']), end='  ')"
-  python bench.py --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('20-step %.0f' % d['value'], end='  ')"
-  python bench.py --no-cpu-baseline --scene grid --width 1920 --height 1080 --spp 64 --steps 12 --warmup 4 --inflight 4 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('config5 %.0f mrays/s (%.2f ms)' % (d['value'], d['ms_per_step']))"
+  python bench.py --no-cpu-baseline --steps 300 --warmup 20 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('inflight %.0f mrays/s (%.4f ms)  sync device %.4f ms  sweep %.0f' % (d['value'], d['ms_per_step'], d['value_dispatch_to_host']['device_ms_per_step'], d['exhaustive_sweep']['value']))"
 done; done
 cp /tmp/keep.so rays1bench_amd/lib/librays1.so
