@@ -631,7 +631,9 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     // waves per frame — per-sample records + r1_resolve_kernel either way, unless r1_set_pixel_mode chose PIXEL mode
     // for the throughput entry point (a lane owns a pixel: no sample records, no resolve launch, ~10 % slower)
     const int big_scene_ = c->n_active > R1_MAX_ACTIVE_10BIT ? 1 : 0;
-    const int mode = variant == 6 ? 0 : r1_trace_mode(variant, big_scene_, throughput_mode ? (c->pixel_mode ? 2 : 0) : 1);
+    static const int tp_mode_env = getenv("R1_TP_MODE") ? atoi(getenv("R1_TP_MODE")) : -1; // tuning experiments
+    const int tp_mode = c->pixel_mode ? 2 : (tp_mode_env >= 0 && tp_mode_env <= 2 ? tp_mode_env : 0);
+    const int mode = variant == 6 ? 0 : r1_trace_mode(variant, big_scene_, throughput_mode ? tp_mode : 1);
     const bool pixel_mode = mode == 2;
     if (!pixel_mode && (rc = ensure(c->samples, (size_t)(c->total_samples ? c->total_samples : 1) * 16)))
         return rc;

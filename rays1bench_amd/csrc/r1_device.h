@@ -17,9 +17,11 @@
 #define R1_GROUP_MAX 4         // spheres per group (level 1 of the sweep tests group bounds)
 #define R1_GROUP_MIN_SPHERES 128 // scenes with fewer active spheres are swept ungrouped
 #define R1_GROUP_RATIO 3.5     // a group's bounding radius stays within this factor of its smallest member radius
-#define R1_SAMPLES_PER_LANE 384    // throughput mode grid sizing: samples each lane should get (see enqueue_frame) ...
-#define R1_MIN_BLOCKS 256          // ... but at least this many workgroups per frame (128 is 2 % better in a long run of 16 frames in flight,
-                                   // 256 is 5 % better over a 20-frame run, whose ramp and drain weigh more) ...
+#define R1_SAMPLES_PER_LANE 150    // throughput mode grid sizing: samples each lane should get (see enqueue_frame): 1200x800x10 -> 256
+                                   // workgroups per frame (128 is 2 % better in a long run of 16 frames in flight, 256 is 5 % better over
+                                   // the 20 frames of a short run, whose ramp and drain weigh more) ...
+#define R1_MIN_BLOCKS 128          // ... but at least this many workgroups per frame (the per-rank frames of a 4- or 8-GPU run:
+                                   // 0.301 ms per frame against 0.329 with 256) ...
 #define R1_SAMPLES_PER_LANE_MIN 32 // ... as long as a lane still gets this many samples
 #define R1_TILE_SPHERES 512    // big-scene sweep: spheres per LDS tile (8 KB in pair layout), two tiles in LDS
 #define R1_TILE_F4 (R1_TILE_SPHERES / 2 * 2) // float4 per tile: 2 per pair of spheres

@@ -1,42 +1,63 @@
 #!/bin/bash
 # tools/profile_round.sh TAG — the round's evidence set, run on the GPU box; results under
 # gpurun_out/prof_TAG/ (copy what should be judged into profiles/rNN/).
-#   1. rocprofv3 --kernel-trace --stats of the default bench command (16 frames in flight)
-#   2. the same with --inflight 1 (one launch at a time: a launch's duration = its share of the chip)
-#   3. HBM traffic of the trace kernel: --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes
-#   4. the bench line itself (with cpu_baseline) and the emulated per-rank load of N-GPU runs
-set -e
-TAG=${1:-r01}
+#   1. rocprofv3 --kernel-trace --stats of the default bench command (16 frames in flight) and of the driver's (--steps 20 --warmup 5)
+#   2. HBM traffic of the trace kernel: --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (default and --pixel-mode)
+#   3. SQ counters of the throughput-mode trace kernel (instruction counts, busy / wait cycles)
+#   4. the bench line itself (with cpu_baseline), the other BASELINE configs on one GPU, emulated per-rank loads
+#   5. diagnostics: traversal counters, per-wave timeline of a synchronous frame, issue-cost and atomic micro-benchmarks
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $OUT/k16 -o k16 --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $OUT/k16.log 2>&1 || echo "k16 failed"
-timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $OUT/k1 -o k1 --output-format csv -- python3 $R/bench.py --no-cpu-baseline --inflight 1 > $OUT/k1.log 2>&1 || echo "k1 failed"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $OUT/k20 -o k20 --output-format csv -- python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 > $OUT/k20.log 2>&1 || echo "k20 failed"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 120 rocprofv3 --pmc $c --kernel-trace -d $OUT/pmc_$c -o p --output-format csv -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 --inflight 1 > $OUT/pmc_$c.log 2>&1 || echo "pmc $c failed"
+  timeout -k 10 120 rocprofv3 --pmc $c --kernel-trace -d $OUT/pmcpix_$c -o p --output-format csv -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 --inflight 1 --pixel-mode > $OUT/pmcpix_$c.log 2>&1 || echo "pmcpix $c failed"
 done
+timeout -k 10 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace -d $OUT/pmc_sq1 -o p --output-format csv -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 --inflight 1 > $OUT/pmc_sq1.log 2>&1 || echo "pmc sq1 failed"
+timeout -k 10 120 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE SQ_ACTIVE_INST_LDS --kernel-trace -d $OUT/pmc_sq2 -o p --output-format csv -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 --inflight 1 > $OUT/pmc_sq2.log 2>&1 || echo "pmc sq2 failed"
 cd $R
 timeout -k 10 300 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err || echo "bench failed"
+timeout -k 10 120 python bench.py --steps 20 --warmup 5 > $OUT/bench_line_driver_command.json 2>/dev/null || echo "bench20 failed"
+timeout -k 10 200 python bench.py --scene medium > $OUT/bench_line_config2_medium.json 2>/dev/null || echo "medium failed"
+timeout -k 10 200 python bench.py --spp 250 --steps 48 --warmup 16 --no-cpu-baseline > $OUT/bench_line_config4_250spp_one_gpu.json 2>/dev/null || echo "250 failed"
+timeout -k 10 300 python bench.py --scene grid --width 1920 --height 1080 --spp 64 --steps 16 --warmup 4 --inflight 4 > $OUT/bench_line_config5_100k_one_gpu.json 2>/dev/null || echo "config5 failed"
+timeout -k 10 200 python bench.py --pixel-mode --no-cpu-baseline > $OUT/bench_line_pixel_mode.json 2>/dev/null || echo "pixel failed"
 for k in 2 4 8; do
   timeout -k 10 120 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --emulate-shards $k 2>/dev/null | tail -1 > $OUT/emulate_shards_$k.json || echo "emulate $k failed"
 done
+timeout -k 10 120 python tools/bvh_stats.py large 1200 800 10 > $OUT/traversal_stats_tree_kernel.txt 2>&1
+timeout -k 10 120 python tools/kernel_stats.py large 1200 800 10 > $OUT/phase_stats_sweep_kernel.txt 2>&1
+timeout -k 10 120 python tools/wave_timeline.py > $OUT/wave_timeline_sync_frame.txt 2>&1
+timeout -k 10 120 python tools/host_costs.py > $OUT/host_costs.txt 2>&1
+timeout -k 10 120 rays1bench_amd/lib/ubench_isa > $OUT/isa_issue_costs.txt 2>&1
+timeout -k 10 120 rays1bench_amd/lib/ubench_atomic > $OUT/atomic_queue_rates.txt 2>&1
 python3 - <<PY
 import csv, glob, json, collections
 out = "$OUT"
-for tag in ("k16", "k1"):
+for tag in ("k16", "k20"):
     for f in glob.glob(f"{out}/{tag}/**/*kernel_stats.csv", recursive=True):
-        print(tag, open(f).read().splitlines()[1][:160])
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    for f in glob.glob(f"{out}/pmc_{c}/**/*counter_collection.csv", recursive=True):
+        print(tag, *open(f).read().splitlines()[:4], sep="\n   ")
+for c in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmcpix_FETCH_SIZE", "pmcpix_WRITE_SIZE", "pmc_sq1", "pmc_sq2"):
+    for f in glob.glob(f"{out}/{c}/**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            acc[(r["Kernel_Name"][:40], r["Counter_Name"])].append(float(r["Counter_Value"]))
+            acc[(r["Kernel_Name"][:44], r["Counter_Name"])].append(float(r["Counter_Value"]))
         for k, v in sorted(acc.items()):
-            print(k, "mean per dispatch", sum(v) / len(v), "n", len(v))
-d = json.loads(open(f"{out}/bench_line.json").read().strip().splitlines()[-1])
-print("bench value", d["value"], "ms", d["ms_per_step"], "cpu", d.get("cpu_baseline", {}).get("value"))
+            print(c, k, "mean per dispatch %.0f" % (sum(v) / len(v)), "n", len(v))
+for name in ("bench_line", "bench_line_driver_command", "bench_line_config2_medium", "bench_line_config4_250spp_one_gpu", "bench_line_config5_100k_one_gpu", "bench_line_pixel_mode"):
+    try:
+        d = json.loads(open(f"{out}/{name}.json").read().strip().splitlines()[-1])
+        print(name, "value %.0f" % d["value"], "ms %.4f" % d["ms_per_step"], "d2h", d.get("value_dispatch_to_host", {}).get("value"), "cpu", d.get("cpu_baseline", {}).get("value"))
+    except Exception as e:
+        print(name, "failed", e)
 for k in (2, 4, 8):
-    e = json.loads(open(f"{out}/emulate_shards_{k}.json").read())
-    print("emulated shards", k, "ms/step", e["ms_per_step"])
+    try:
+        e = json.loads(open(f"{out}/emulate_shards_{k}.json").read())
+        print("emulated shards", k, "ms/step", e["ms_per_step"])
+    except Exception as e:
+        print("emulate", k, "failed", e)
 PY
