@@ -20,6 +20,10 @@
 //     --gather host: one host thread + r1_context per device, each device copies its own tiles
 //         into the caller's pixel buffer (also works oversubscribed: N contexts on fewer GPUs)
 // bench.py's one-process-per-GPU form (torch.distributed) gathers the same records.
+// --backend hip (default) | cpu-step1 | cpu-step12: the reference's two single-thread CPU stages
+// (r1_cpu_backends.cpp) behind the same benchmark(), for the README-style table
+// (README.md:38-84).  Named backends of this program only — never a fallback: with --backend hip and no
+// usable device the program exits with an error.
 
 #include <stdint.h>
 #include <stdio.h>
@@ -57,6 +61,11 @@ static uint32_t g_seed = 10001;
 static int g_device = 0;
 static int g_variant = R1_VARIANT_DEFAULT;
 static int g_devices = 1;
+static int g_backend = 0; // 0 hip, 1 cpu-step1, 12 cpu-step12
+int r1cpu_step12_render(const r1_scene *scene, const r1_camera *cam, int width, int height, int spp, int max_bounces, uint8_t *rgb,
+                        uint64_t *num_rays); // r1_cpu_backends.cpp
+int r1cpu_step1_render(int scene_kind, const r1_scene *scene, const r1_camera *cam, int width, int height, int spp, uint8_t *rgb,
+                       uint64_t *num_rays);
 static std::vector<r1_context *> g_ctx; // one per device in use (--gather host)
 static r1_multi *g_multi = nullptr;     // --gather rccl
 static int g_gather = -1;               // -1 auto, 0 host, 1 rccl
@@ -69,6 +78,7 @@ class Scene // rayweek1.cpp:539-549: owns its spheres/materials, deleted by benc
 {
   public:
     r1_host_scene *host = nullptr;
+    int kind = 0; // R1_SCENE_*
     const r1_scene *hitables = nullptr;
     const r1_camera *camera = nullptr;
     ~Scene() { r1_host_scene_destroy(host); }
@@ -82,6 +92,7 @@ static Scene *make_scene(int kind)
         fprintf(stderr, "scene build failed: %s\n", r1_last_error());
         exit(1);
     }
+    s->kind = kind;
     s->hitables = r1_host_scene_spheres(s->host);
     s->camera = r1_host_scene_camera(s->host);
     return s;
@@ -106,6 +117,33 @@ RESULT benchmark(Scene *scene, Pix *pixels, bool write_tga, const char *scene_na
     p.shard = 0, p.num_shards = 1;
     p.variant = g_variant;
 
+    if (g_backend != 0)
+    {
+        // the reference's single-thread CPU stages (r1_cpu_backends.cpp), same timer span and report
+        if (g_backend == 12)
+            r1cpu_step12_render(scene->hitables, scene->camera, g_screen_w, g_screen_h, g_spp, g_max_bounces, &pixels[0].r, &result.num_rays);
+        else
+            r1cpu_step1_render(scene->kind, scene->hitables, scene->camera, g_screen_w, g_screen_h, g_spp, &pixels[0].r, &result.num_rays);
+        result.elapsed_seconds = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+        g_device_seconds.push_back(0.0);
+        memset(&g_last_info, 0, sizeof(g_last_info));
+        g_last_info.spheres_padded = (int32_t)scene->hitables->count;
+        printf("%s\n", scene_name);
+        printf("elapsed time:   %.3fs\n", result.elapsed_seconds);
+        printf("total samples:  %llu\n", (unsigned long long)((uint64_t)g_screen_w * g_screen_h * g_spp));
+        printf("total rays:     %llu\n", (unsigned long long)result.num_rays);
+        printf("mrays/s:        %0.2f\n", result.get_mrays_per_sec());
+        printf("backend:        %s (1 host thread, no GPU)\n", g_backend == 12 ? "cpu-step12" : "cpu-step1");
+        printf("\n");
+        delete scene; // rayweek1.cpp:905
+        if (write_tga)
+        {
+            char filename[128];
+            snprintf(filename, sizeof(filename), "out_%s.tga", scene_name);
+            r1_tga_write_rgb24(filename, g_screen_w, g_screen_h, &pixels[0].r);
+        }
+        return result;
+    }
     if (g_multi)
     {
         // tile split over the devices + one RCCL all-gather, behind one call
@@ -298,21 +336,28 @@ int main(int argc, const char *argv[])
             g_devices = atoi(argv[++i]);
         else if (strcmp(argv[i], "--variant") == 0 && i + 1 < argc)
             g_variant = atoi(argv[++i]);
+        else if (strcmp(argv[i], "--backend") == 0 && i + 1 < argc)
+        {
+            const char *b = argv[++i];
+            g_backend = strcmp(b, "hip") == 0 ? 0 : (strcmp(b, "cpu-step1") == 0 ? 1 : (strcmp(b, "cpu-step12") == 0 ? 12 : -1));
+        }
         else if (strcmp(argv[i], "--gather") == 0 && i + 1 < argc)
         {
             const char *g = argv[++i];
             g_gather = strcmp(g, "rccl") == 0 ? 1 : (strcmp(g, "host") == 0 ? 0 : -2);
         }
     }
-    if (g_screen_w <= 0 || g_screen_h <= 0 || g_spp <= 0 || g_devices < 1 || g_devices > 64 || g_gather == -2)
+    if (g_screen_w <= 0 || g_screen_h <= 0 || g_spp <= 0 || g_devices < 1 || g_devices > 64 || g_gather == -2 || g_backend < 0)
     {
-        fprintf(stderr, "bad --width/--height/--spp/--devices/--gather\n");
+        fprintf(stderr, "bad --width/--height/--spp/--devices/--gather/--backend\n");
         return 1;
     }
 
     // HIP context creation stays outside the timed region and is shared by all -n runs.
     // Devices wrap around the visible ones, so --devices 2 also works (oversubscribed) on one GPU.
-    const int visible = r1_device_count();
+    const int visible = g_backend == 0 ? r1_device_count() : 0;
+    if (g_backend != 0)
+        g_devices = 0, g_gather = 0; // the CPU stages touch no device
     if (g_gather == -1)
         g_gather = g_devices > 1 && g_device + g_devices <= visible ? 1 : 0; // RCCL needs distinct devices
     if (g_gather == 1)
@@ -340,7 +385,7 @@ int main(int argc, const char *argv[])
     Pix *pixels = new Pix[(size_t)g_screen_w * g_screen_h];
     memset(pixels, 0, (size_t)g_screen_w * g_screen_h * sizeof(pixels[0]));
 
-    const char *version = "hip";
+    const char *version = g_backend == 0 ? "hip" : (g_backend == 12 ? "cpu-step12" : "cpu-step1");
 
     for (int i = 0; i < num_runs; ++i)
         results[i] = benchmark(create_small_scene(), pixels, write_tga, "small");
