@@ -384,7 +384,7 @@ def main():
                        6: "wavefront: generate / intersect / shade kernels, box tree (comparison build)"}[info["kernel"]]
         kernel_s = trace_ms_sum / max(frames, 1) * 1e-3  # average launch duration, HIP events on the stream of each launch
         overlap = trace_ms_sum * 1e-3 / elapsed           # launches of different frames overlap (frames in flight)
-        traffic, traffic_source = None, None
+        traffic, traffic_source, valu_instr, valu_source = None, None, None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath) and info["kernel"] != 6:
             try:
@@ -392,6 +392,8 @@ def main():
                 if tj.get("workload") == f"{args.scene} {w}x{h}x{spp}" and n == 1 and tj.get("kernel_variant") == info["kernel"]:
                     traffic = tj.get("hbm_bytes_per_launch")
                     traffic_source = f"profiles/pmc_traffic.json: {tj.get('source', 'rocprofv3 --pmc passes')} (not measured by this run)"
+                    valu_instr = tj.get("valu_wave_instructions_per_launch")
+                    valu_source = f"{tj.get('valu_source', 'profiles/')} (not measured by this run)"
             except Exception:
                 traffic = None
         flop = work.get("flop_per_launch") if work else None
@@ -413,6 +415,13 @@ def main():
             "launch_overlap": overlap,
             "achieved_aggregate": (flop * frames / elapsed / 1e12) if flop else None,
             "frac_aggregate": (flop * frames / elapsed / 1e12 / FP32_VECTOR_PEAK_TF) if flop else None,
+            # what binds the kernel: VALU wave-instructions issued (PMC) against one per two cycles per SIMD
+            "valu_issue": {"wave_instructions_per_launch": valu_instr, "source": valu_source,
+                           "peak": 1024 * 2.4e9 / 2 / 1e12, "unit": "T wave-instructions/s (256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles)",
+                           "achieved_aggregate": (valu_instr * frames / elapsed / 1e12) if valu_instr else None,
+                           "frac_aggregate": (valu_instr * frames / elapsed / 1e12 / (1024 * 2.4e9 / 2 / 1e12)) if valu_instr else None,
+                           "note": "the instructions of this kernel issue in 2.7 (fp32 add / mul / fma) to 4.4 cycles (min / max / compare / "
+                                   "select / convert): profiles/r02/isa_issue_costs.txt, so ~0.6 of the 2-cycle peak is a busy pipe"},
             "hbm": {"peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "achieved": (traffic / kernel_s / 1e9) if traffic else None,
                     "achieved_aggregate": (traffic * frames / elapsed / 1e9) if traffic else None,
