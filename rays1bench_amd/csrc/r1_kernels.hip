@@ -249,9 +249,13 @@ __device__ __forceinline__ int wave_inclusive_scan(int v, const int lane)
 // `total` (lane, group) pairs are in `pairs`.  SLOTS == R1_GROUP_MAX: each pair expands to its
 // member slots — 16 pairs x 4 members fill a trip, a lane takes pair (base + lane) / 4, member
 // lane % 4.  SLOTS == 1: the pairs are single-sphere groups, one lane each.
+// `rays` (optional): this wave's ray table in LDS, component c of lane l at rays[c * R1_BLOCK + l] — a lane then fetches its
+// owner's ray with six ds_read_b32 (8 issue cycles each) instead of six ds_bpermute_b32 (24).  The table overlays the flag
+// words / candidate lists, which are dead once the pair list is built.
 template <bool STATS, typename IDX, int SLOTS>
 __device__ __forceinline__ void exact_trips(const R1DeviceScene &S, const V3 o, const V3 d, const int total, const IDX *pairs,
-                                            unsigned long long *best /* this wave's [64] */, const int lane, unsigned long long *wstat)
+                                            unsigned long long *best /* this wave's [64] */, const int lane, unsigned long long *wstat,
+                                            const float *rays = nullptr)
 {
     constexpr int IDX_BITS = PairBits<IDX>::value;
     constexpr int SHIFT = SLOTS == 1 ? 0 : 2;
@@ -268,8 +272,16 @@ __device__ __forceinline__ void exact_trips(const R1DeviceScene &S, const V3 o, 
         const uint32_t grp = pr & ((1u << IDX_BITS) - 1u);
         const uint32_t idx = have_pair ? S.members[(size_t)grp * R1_GROUP_MAX + (SLOTS == 1 ? 0 : (lane & (R1_GROUP_MAX - 1)))] : 0xFFFFFFFFu;
         V3 ro, rd;
-        ro.x = __shfl(o.x, owner, 64), ro.y = __shfl(o.y, owner, 64), ro.z = __shfl(o.z, owner, 64);
-        rd.x = __shfl(d.x, owner, 64), rd.y = __shfl(d.y, owner, 64), rd.z = __shfl(d.z, owner, 64);
+        if (rays)
+        {
+            ro = mk(rays[0 * R1_BLOCK + owner], rays[1 * R1_BLOCK + owner], rays[2 * R1_BLOCK + owner]);
+            rd = mk(rays[3 * R1_BLOCK + owner], rays[4 * R1_BLOCK + owner], rays[5 * R1_BLOCK + owner]);
+        }
+        else
+        {
+            ro.x = __shfl(o.x, owner, 64), ro.y = __shfl(o.y, owner, 64), ro.z = __shfl(o.z, owner, 64);
+            rd.x = __shfl(d.x, owner, 64), rd.y = __shfl(d.y, owner, 64), rd.z = __shfl(d.z, owner, 64);
+        }
         if (idx != 0xFFFFFFFFu)
         {
             const float t = exact_offer(((const f4 *)S.exact)[idx], ro, rd);
@@ -278,6 +290,17 @@ __device__ __forceinline__ void exact_trips(const R1DeviceScene &S, const V3 o, 
         }
     }
     __builtin_amdgcn_wave_barrier();
+}
+
+// writes this lane's ray into the wave's LDS ray table (see exact_trips); returns the wave's base pointer
+__device__ __forceinline__ const float *publish_rays(uint32_t *scratch /* [>= 6][R1_BLOCK] */, const V3 o, const V3 d, const int tid)
+{
+    float *t = (float *)scratch;
+    __builtin_amdgcn_wave_barrier(); // every lane has read what it needed from the scratch rows
+    t[0 * R1_BLOCK + tid] = o.x, t[1 * R1_BLOCK + tid] = o.y, t[2 * R1_BLOCK + tid] = o.z;
+    t[3 * R1_BLOCK + tid] = d.x, t[4 * R1_BLOCK + tid] = d.y, t[5 * R1_BLOCK + tid] = d.z;
+    __builtin_amdgcn_wave_barrier();
+    return t + (tid & ~63);
 }
 
 // Append path (big scenes): every lane holds `cnt` flagged group indices in cand[j][tid].
@@ -292,8 +315,9 @@ __device__ __forceinline__ void cooperative_exact(const R1DeviceScene &S, const 
     const int excl = incl - cnt;
     for (int j = 0; j < cnt; ++j)
         pairs[excl + j] = (IDX)(((uint32_t)lane << IDX_BITS) | cand[j * R1_BLOCK + tid]);
-    __builtin_amdgcn_wave_barrier();
-    exact_trips<STATS, IDX, R1_GROUP_MAX>(S, o, d, total, pairs, best, lane, wstat);
+    static_assert(R1_CAND_CAP >= 6, "the ray table needs six rows of the candidate list");
+    const float *rays = publish_rays(const_cast<uint32_t *>(cand), o, d, tid);
+    exact_trips<STATS, IDX, R1_GROUP_MAX>(S, o, d, total, pairs, best, lane, wstat, rays);
 }
 
 // Bit path (<= 1023 groups): every lane holds `nwords` 32-bit flag words in words[w][tid]; bit
@@ -345,9 +369,10 @@ __device__ __forceinline__ void cooperative_bits(const R1DeviceScene &S, const V
                     pairs[pos_s--] = v;
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        exact_trips<STATS, IDX, R1_GROUP_MAX>(S, o, d, total_m, pairs, best, lane, wstat);
-        exact_trips<STATS, IDX, 1>(S, o, d, total_s, pairs + (CAP - total_s), best, lane, wstat);
+        static_assert(R1_BIT_WORDS >= 6, "the ray table needs six rows of the flag words");
+        const float *rays = publish_rays(const_cast<uint32_t *>(words), o, d, tid); // the words of this batch are consumed
+        exact_trips<STATS, IDX, R1_GROUP_MAX>(S, o, d, total_m, pairs, best, lane, wstat, rays);
+        exact_trips<STATS, IDX, 1>(S, o, d, total_s, pairs + (CAP - total_s), best, lane, wstat, rays);
         return;
     }
     // more pairs than the list holds: work the flag words off in segments of CAP / 64 bits, whose
