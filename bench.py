@@ -384,7 +384,7 @@ def main():
                        6: "wavefront: generate / intersect / shade kernels, box tree (comparison build)"}[info["kernel"]]
         kernel_s = trace_ms_sum / max(frames, 1) * 1e-3  # average launch duration, HIP events on the stream of each launch
         overlap = trace_ms_sum * 1e-3 / elapsed           # launches of different frames overlap (frames in flight)
-        traffic, traffic_source, valu_instr, valu_source = None, None, None, None
+        traffic, traffic_source, valu_instr, valu_source, valu_lanes = None, None, None, None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath) and info["kernel"] != 6:
             try:
@@ -393,6 +393,7 @@ def main():
                     traffic = tj.get("hbm_bytes_per_launch")
                     traffic_source = f"profiles/pmc_traffic.json: {tj.get('source', 'rocprofv3 --pmc passes')} (not measured by this run)"
                     valu_instr = tj.get("valu_wave_instructions_per_launch")
+                    valu_lanes = tj.get("valu_active_lane_fraction")
                     valu_source = f"{tj.get('valu_source', 'profiles/')} (not measured by this run)"
             except Exception:
                 traffic = None
@@ -417,6 +418,7 @@ def main():
             "frac_aggregate": (flop * frames / elapsed / 1e12 / FP32_VECTOR_PEAK_TF) if flop else None,
             # what binds the kernel: VALU wave-instructions issued (PMC) against one per two cycles per SIMD
             "valu_issue": {"wave_instructions_per_launch": valu_instr, "source": valu_source,
+                           "active_lane_fraction": valu_lanes,  # SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): lanes doing work per issued instruction
                            "peak": 1024 * 2.4e9 / 2 / 1e12, "unit": "T wave-instructions/s (256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles)",
                            "achieved_aggregate": (valu_instr * frames / elapsed / 1e12) if valu_instr else None,
                            "frac_aggregate": (valu_instr * frames / elapsed / 1e12 / (1024 * 2.4e9 / 2 / 1e12)) if valu_instr else None,

@@ -45,6 +45,8 @@ traffic = {"workload": "large 1200x800x10", "kernel": "r1_trace_kernel<4,false,f
            "other_kernels": {"synchronous frame (MODE 1)": hb(fl, wl), "exhaustive sweep (MODE 0)": hb(fs, ws), "PIXEL mode (MODE 2, r1_set_pixel_mode)": hb(fp, wp)},
            "valu_wave_instructions_per_launch": counters["tree kernel, frames in flight (MODE 0, 254 workgroups)"]["SQ_INSTS_VALU"],
            "valu_source": f"profiles/{tag}/pmc_counters_tree_kernel.json (rocprofv3 --pmc SQ_INSTS_VALU ..., same command)",
+           "valu_active_lane_fraction": counters["tree kernel, frames in flight (MODE 0, 254 workgroups)"]["SQ_THREAD_CYCLES_VALU"]
+           / (counters["tree kernel, frames in flight (MODE 0, 254 workgroups)"]["SQ_ACTIVE_INST_VALU"] * 64),
            "note": "the trace kernel writes one 16-byte record per pixel-sample (9.6 M x 16 B = 153.6 MB) and reads the node table + sphere pairs through L1/L2: "
                    "HBM reads are noise.  The synchronous-frame kernel writes more (64-sample chunks per wave: more partial lines).  PIXEL mode writes the resolved pixels only."}
 json.dump(traffic, open(f"{root}/profiles/pmc_traffic.json", "w"), indent=1)
