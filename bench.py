@@ -445,7 +445,8 @@ def main():
                        "parallelism": f"tile-split x{n}" + (" + one RCCL all-gather per frame (pixels + ray counts)" if n > 1 else ""),
                        "value_mode": f"{len(slots)} frames in flight (one stream + context each), scene and image resident in HBM",
                        "workgroups": info["blocks"], "threads_per_workgroup": info["threads_per_block"],
-                       "frames_in_flight": len(slots), "host_submit_ms_per_step": submit / args.steps * 1e3,
+                       "frames_in_flight": len(slots), "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "host_submit_ms_per_step": submit / args.steps * 1e3,
                        "kernel": kernel_name,
                        **({"bvh": {"nodes": info["bvh_nodes"], "leaves": info["bvh_leaves"], "depth": info["bvh_depth"]}} if is_tree else {})},
             "roofline": roofline,

@@ -680,6 +680,9 @@ __device__ __forceinline__ void trav_start(Trav &t)
     t.cur = 0u, t.sp = 0, t.best = FLT_MAX, t.best_id = 0xFFFFFFFFu;
 }
 
+#ifndef R1_CARRY_DIV
+#define R1_CARRY_DIV 4u // a walk phase ends when at most 1 / R1_CARRY_DIV of the live lanes are still walking
+#endif
 // Advances every lane whose walk is not complete.  CARRY = false: until all walks are complete (the
 // classic while-while loop).  CARRY = true: returns as soon as at most a quarter of the `n_alive` live
 // lanes of the wave are still walking; those lanes keep their state and go on in the next call, next
@@ -711,7 +714,7 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
         const unsigned long long walking = __ballot(cur != R1_BVH_DONE);
         if (walking == 0ull)
             break;
-        if (CARRY && 4u * (uint32_t)__popcll(walking) <= n_alive)
+        if (CARRY && R1_CARRY_DIV * (uint32_t)__popcll(walking) <= n_alive)
             break; // (n_alive <= 3: never true while a lane walks, so the last walks of a wave run to their end)
         if (MAJORITY)
         {
