@@ -162,7 +162,7 @@ struct Builder
         // spheres more than R1_BVH_PEEL_RATIO (4) x the node's median radius become ONE leaf here and the rest keeps tight
         // boxes: large scene 24.3 -> 26.5 Grays/s, 100 004-sphere scene 12.2 -> 12.8 (tools: R1_BVH_PEEL=0 switches it off).
         static const int peel_env = getenv("R1_BVH_PEEL") ? atoi(getenv("R1_BVH_PEEL")) : 1;
-        if (peel_env && !force_median && n > 2u * (uint32_t)leaf_max)
+        if (peel_env && !force_median && depth + need + 2 < R1_BVH_STACK && n > 2u * (uint32_t)leaf_max) // (a peel costs a level)
         {
             std::vector<double> rs(n);
             for (uint32_t i = 0; i < n; ++i)

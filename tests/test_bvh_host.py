@@ -325,3 +325,27 @@ def test_describe_filters_like_set_scene_and_bounds_follow_the_larger_radius():
     arrs["inv_radius"][0] = F(np.nan)
     info2 = binding.BvhInfo()
     assert binding.lib().r1_bvh_describe(C.byref(cs), 0, C.byref(info2), None, 0, None, 0) == binding.R1_EINVAL
+
+
+def test_outlier_peeling_keeps_the_lattice_boxes_flat_and_the_depth_bounded():
+    """r1_bvh.cpp peels up to one leaf's worth of spheres much larger than the node's median radius into a leaf of their own
+    before the centroid split.  Large scene: the root is [ground + the three r = 2 balls | the lattice], and the lattice's box
+    is as flat as the lattice (0.5 high, not 2.7); a tower of ever larger spheres cannot push the depth past the stack."""
+    sc = r1.create_large_scene(1200, 800)
+    a = sc.arrays()
+    info, nodes, ids = binding.bvh_describe(sc.spheres.contents)
+    root = nodes[0].view(np.uint32)
+    big = sorted(np.argsort(a["radius_sq"])[-4:].tolist())
+    leaf = [int(r) for r in (root[14], root[15]) if r & LEAF]
+    assert len(leaf) == 1 and sorted(ids[list(leaf_slots(leaf[0]))].tolist()) == big
+    lattice_child = 1 if (root[14] & LEAF) else 0
+    assert nodes[0][E[lattice_child][1]] < 0.6  # half height of the lattice's box
+    # adversarial: radii 4^i (every sphere an outlier of the rest) + a crowd of small ones
+    rng = np.random.default_rng(9)
+    n_small = 600
+    rad = np.concatenate([np.full(n_small, 0.01), 0.05 * 4.0 ** np.arange(20)])
+    c = np.concatenate([rng.uniform(-1, 1, (n_small, 3)), rng.uniform(-1, 1, (20, 3))])
+    cs, arrs, mt = _raw_scene(c, rad)
+    info2, nodes2, ids2 = binding.bvh_describe(cs)
+    assert sorted(ids2[ids2 != EMPTY].tolist()) == list(range(len(rad)))
+    assert 1 <= info2["depth"] <= info2["stack_entries"]
