@@ -54,7 +54,7 @@ class LaunchInfo(C.Structure):
 
 class BvhInfo(C.Structure):
     _fields_ = [("nodes", C.c_int32), ("leaves", C.c_int32), ("depth", C.c_int32), ("stack_entries", C.c_int32), ("spheres", C.c_int32),
-                ("pairs", C.c_int32)]
+                ("pairs", C.c_int32), ("centre", C.c_float * 3)]
 
 
 def make_params(width, height, spp, seed=10001, max_bounces=50, tile_w=32, tile_h=32, shard=0, num_shards=1, variant=0):
@@ -349,7 +349,9 @@ def bvh_describe(cscene, leaf_max=0):
     ids = np.zeros(max(2 * info.pairs, 2), np.uint32)
     _check(lib().r1_bvh_describe(C.byref(cscene), leaf_max, C.byref(info), nodes.ctypes.data_as(_f32p), nodes.size,
                                  ids.ctypes.data_as(C.POINTER(C.c_uint32)), ids.size))
-    return {k: int(getattr(info, k)) for k, _ in BvhInfo._fields_}, nodes, ids[:2 * info.pairs]
+    d = {k: int(getattr(info, k)) for k, _ in BvhInfo._fields_ if k != "centre"}
+    d["centre"] = np.array(list(info.centre), np.float32)
+    return d, nodes, ids[:2 * info.pairs]
 
 
 class RESULT:

@@ -14,13 +14,24 @@
 // sign bit therefore has its centre within sqrt(r^2 + E1) <= r_eff + E1 / (2 r_eff) of the
 // ray's line (r_eff = max(r, r_floor); the r_floor/2 this costs a degenerate sphere is added
 // to the pad), and the point at its offered t lies within that distance + 5 u |v| of the
-// centre.  A child box is stored as centre m and half extent e; the kernel inflates it by
-//      pad = w2 * |m - o|^2 + k
+// centre.  A child box is stored as centre m and half extent e and has to be inflated by at least
+//      pad_min = w2 * |m - o|^2 + k
 // with  w2 = 2 * (40 u * max_i 1 / (2 r_eff,i)) + 2^-19   and   k = w2 * h^2 + 2^-20 + ...,
 // h = max_i |c_i - m|, using |v|^2 <= 2 |m - o|^2 + 2 h^2.  The 2^-19 / 2^-20 terms cover the
 // rounding of the slab test itself: products and differences (<= 6u D in position units, D the
 // largest distance involved) and the 1-ulp reciprocals of the direction (v_rcp_f32, <= 2^-22 D),
 // together < 2^-20.7 D <= 2^-21.7 (1 + D^2), against a budget of 2^-20 (1 + D^2).
+//
+// What the kernel evaluates (r1_kernels.hip::bvh_box) is ONE fused multiply-add per node,
+//      pad = A * R2 + K,      R2 = |o - C|^2 computed once per ray,
+// C a fixed point of the scene (the per-axis median of the sphere centres, R1Bvh::centre), and
+// A = 2 w2 + u, K = k + 2 w2 g^2 + u (1 + |C|_1), g = the larger |m - C| of the node's two children:
+// |m - o|^2 <= 2 |o - C|^2 + 2 |m - C|^2, so pad >= pad_min for both children, at the price of boxes
+// a few 1e-2 units wider than necessary (large scene: pad ~0.03 next to r = 0.45).  The u terms pay for
+// the slab test's own form a = m * (1/d) - o * (1/d) (fused, o * (1/d) rounded once per ray): next to
+// the errors budgeted above it adds u |o| (1 + u) in position units, and |o| <= |o - C| + |C| <=
+// (1 + R2) / 2 + |C|.  A and K are rounded up with 2^-18 relative headroom for the fp32 evaluation
+// of R2 (3 u) and of the fused multiply-add (u).
 // Every constant is rounded up.  Extra visits are harmless: leaves apply the reference's rule.
 #include <hip/hip_runtime.h>
 
@@ -41,6 +52,7 @@ struct R1Bvh
     std::vector<uint32_t> ids;  // 2 per pair: active index, 0xFFFFFFFF for the partner of an odd sphere
     int max_depth = 0;          // inner nodes on the longest root-to-leaf path
     uint32_t n_leaves = 0;
+    float centre[3] = {0, 0, 0}; // C of the pad formula (see above)
 };
 
 namespace
@@ -91,6 +103,7 @@ struct Builder
     std::vector<uint32_t> order;
     R1Bvh *out;
     int leaf_max;
+    double centre[3]; // C of the pad formula, == out->centre
 
     static const uint32_t LEAF = 0x80000000u;
 
@@ -275,12 +288,24 @@ struct Builder
         encode(b0, m0, e0, w0, k0);
         encode(b1, m1, e1, w1, k1);
         float *p = &out->nodes[16 * (size_t)node];
-        const float w2 = round_up(std::max(w0, w1)), k = round_up(std::max(k0, k1));
-        // {m0x m1x m0y m1y} {m0z m1z e0x e1x} {e0y e1y e0z e1z} {w2 k child0 child1}
+        // pad = A |o - C|^2 + K (see the header): >= w2 |m - o|^2 + k for both children
+        double g2 = 0;
+        for (const float *m : {m0, m1})
+        {
+            double q = 0;
+            for (int a = 0; a < 3; ++a)
+                q += ((double)m[a] - centre[a]) * ((double)m[a] - centre[a]);
+            g2 = std::max(g2, q);
+        }
+        const double u = ldexp(1.0, -24), w2 = std::max(w0, w1), k = std::max(k0, k1);
+        const double c1n = std::fabs(centre[0]) + std::fabs(centre[1]) + std::fabs(centre[2]);
+        const double head = 1.0 + ldexp(1.0, -18);
+        const float A = round_up((2.0 * w2 + u) * head), K = round_up((k + 2.0 * w2 * g2 + u * (1.0 + c1n)) * head);
+        // {m0x m1x m0y m1y} {m0z m1z e0x e1x} {e0y e1y e0z e1z} {A K child0 child1}
         p[0] = m0[0], p[1] = m1[0], p[2] = m0[1], p[3] = m1[1];
         p[4] = m0[2], p[5] = m1[2], p[6] = e0[0], p[7] = e1[0];
         p[8] = e0[1], p[9] = e1[1], p[10] = e0[2], p[11] = e1[2];
-        p[12] = w2, p[13] = k;
+        p[12] = A, p[13] = K;
         memcpy(&p[14], &c0, 4);
         memcpy(&p[15], &c1, 4);
     }
@@ -322,6 +347,20 @@ void r1_build_bvh(uint32_t na, const float *cx, const float *cy, const float *cz
         s.kmax = 1.0 / (2.0 * r_eff);
         s.rmax = r;
         s.floor_pad = r_test < r_floor ? 0.5 * r_floor : 0.0;
+    }
+    // C: the per-axis median of the centres (the ground sphere's centre, 1000 units below, must not drag it away)
+    for (int k = 0; k < 3; ++k)
+    {
+        const float *src = k == 0 ? cx : (k == 1 ? cy : cz);
+        std::vector<float> v(src, src + na);
+        double med = 0;
+        if (na)
+        {
+            std::nth_element(v.begin(), v.begin() + na / 2, v.end());
+            med = v[na / 2];
+        }
+        out.centre[k] = (float)med;
+        B.centre[k] = (double)out.centre[k]; // exactly the fp32 value the kernel subtracts
     }
     // the root is node 0
     out.nodes.resize(16);
@@ -435,6 +474,8 @@ extern "C" int r1_bvh_describe(const r1_scene *s, int32_t leaf_max, r1_bvh_info 
     info->depth = b.max_depth;
     info->stack_entries = R1_BVH_STACK;
     info->spheres = (int32_t)na;
+    for (int k = 0; k < 3; ++k)
+        info->centre[k] = b.centre[k];
     if (nodes_out)
     {
         if (nodes_cap < b.nodes.size())

@@ -38,6 +38,7 @@ struct R1Bvh
     std::vector<uint32_t> ids;
     int max_depth = 0;
     uint32_t n_leaves = 0;
+    float centre[3] = {0, 0, 0};
 };
 void r1_build_bvh(uint32_t na, const float *cx, const float *cy, const float *cz, const float *rsq, const double *rbound, int leaf_max,
                   R1Bvh &out);
@@ -100,6 +101,7 @@ struct r1_context
     uint32_t wave_log_waves = 0;
     uint32_t n_bvh_nodes = 0, n_bvh_leaves = 0;
     int bvh_depth = 0;
+    float bvh_centre[3] = {0, 0, 0};
     uint32_t n_active = 0, n_sweep = 0, n_padded_scene = 0, n_groups = 0, n_multi = 0;
     std::vector<uint32_t> active_to_scene;
     R1DeviceCamera cam;
@@ -523,6 +525,9 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
     c->n_bvh_nodes = (uint32_t)(bvh.nodes.size() / 16);
     c->n_bvh_leaves = bvh.n_leaves;
     c->bvh_depth = bvh.max_depth;
+    memset(c->occupancy, 0, sizeof(c->occupancy)); // the tree kernels' dynamic LDS follows the scene
+    for (int k = 0; k < 3; ++k)
+        c->bvh_centre[k] = bvh.centre[k];
     for (int &o : c->occupancy)
         o = 0; // the tree kernels' LDS footprint follows the tree depth
     c->n_groups = ng;
@@ -630,7 +635,8 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     // kernel mode: the host-returning entry points run in latency mode, the throughput entry point with few long-lived
     // waves per frame — per-sample records + r1_resolve_kernel either way, unless r1_set_pixel_mode chose PIXEL mode
     // for the throughput entry point (a lane owns a pixel: no sample records, no resolve launch, ~10 % slower)
-    const int big_scene_ = c->n_active > R1_MAX_ACTIVE_10BIT ? 1 : 0;
+    // big-scene kernels: > 1023 hittable spheres (10-bit hit indices), or — tree kernels — a node table too large for LDS
+    const int big_scene_ = (c->n_active > R1_MAX_ACTIVE_10BIT || ((variant == 4 || variant == 5) && c->n_bvh_nodes > R1_NODES_LDS_MAX)) ? 1 : 0;
     static const int tp_mode_env = getenv("R1_TP_MODE") ? atoi(getenv("R1_TP_MODE")) : -1; // tuning experiments
     const int tp_mode = c->pixel_mode ? 2 : (tp_mode_env >= 0 && tp_mode_env <= 2 ? tp_mode_env : 0);
     const int mode = variant == 6 ? 0 : r1_trace_mode(variant, big_scene_, throughput_mode ? tp_mode : 1);
@@ -651,6 +657,8 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     a.scene.bvh_nodes = (const float4 *)c->bvh_nodes.p;
     a.scene.bvh_prims = (const float4 *)c->bvh_prims.p;
     a.scene.bvh_ids = (const uint32_t *)c->bvh_ids.p;
+    for (int k = 0; k < 3; ++k)
+        a.scene.bvh_centre[k] = c->bvh_centre[k];
     a.cam = c->cam;
     a.width = p->width, a.height = p->height, a.spp = p->spp, a.max_bounces = p->max_bounces;
     a.seed = p->seed;
@@ -676,14 +684,17 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     a.num_rays = (unsigned long long *)d_rays;
     a.stats = (variant == 3 || variant == 5) ? (unsigned long long *)((char *)c->counters.p + 128) : nullptr;
 
-    // BIG kernels: 32-bit hit indices and the attenuation stack in a global workspace (the packed
-    // LDS stack holds 10-bit indices).  Tried for the tree kernel on small scenes too (more
-    // workgroups per CU): 15 % slower.
-    const int big = c->n_active > R1_MAX_ACTIVE_10BIT ? 1 : 0;
+    // BIG kernels: 32-bit hit indices, the attenuation stack in a global workspace (the packed
+    // LDS stack holds 10-bit indices) and the tree's node table through the vector L1.  Tried for the
+    // tree kernel on small scenes too (more workgroups per CU): 15 % slower.  The small-scene tree
+    // kernels keep the first 3 * R1_STACK_LDS_WORDS stack entries in LDS and use the workspace beyond.
+    const int big = big_scene_;
     a.bvh_depth = c->bvh_depth > 0 ? c->bvh_depth : 1;
+    a.bvh_lds_f4 = ((variant == 4 || variant == 5) && !big) ? 4u * c->n_bvh_nodes : 0u; // the workgroups' LDS copy of the node table
     const int occ_slot = variant + 8 * big + 16 * mode;
     if (c->occupancy[occ_slot] == 0)
-        R1_HIP(r1_trace_occupancy(variant, big, mode, (variant == 4 || variant == 5) ? (size_t)a.bvh_depth * R1_BLOCK * 4 : 0,
+        R1_HIP(r1_trace_occupancy(variant, big, mode,
+                                  (variant == 4 || variant == 5) ? (size_t)a.bvh_depth * R1_BLOCK * 4 + (size_t)a.bvh_lds_f4 * 16 : 0,
                                   &c->occupancy[occ_slot]));
     int per_cu = c->occupancy[occ_slot];
     if (per_cu < 1)
@@ -774,7 +785,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
         if (c->ring_used < c->ring_frames)
             ++c->ring_used;
     }
-    if (big)
+    if (big || (R1_STACK_LDS_WORDS < R1_STACK_WORDS && (variant == 4 || variant == 5)))
     {
         if ((rc = ensure(c->gstack, (size_t)R1_STACK_ENTRIES * (size_t)blocks * R1_BLOCK * 4)))
             return rc;

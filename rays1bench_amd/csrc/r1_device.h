@@ -11,6 +11,11 @@
 #define R1_PAIR_CAP 1024    // (lane, sphere) pairs of one wave, big scenes: 64 lanes x R1_CAND_CAP
 #define R1_PAIR_CAP_SMALL 512 // same, small scenes (bit path): 4 KB less LDS per workgroup = a fifth workgroup per CU
 #define R1_STACK_WORDS 17   // ceil(51 / 3) packed 10-bit hit indices per lane (max_bounces <= 51)
+#ifndef R1_STACK_LDS_WORDS
+#define R1_STACK_LDS_WORDS 8  // tree kernel, small scenes: words of the packed stack kept in LDS (24 entries); deeper entries (rare) go to
+#endif                        // the global workspace.  8 KB instead of 17: room for the node table at 6 workgroups per CU (4: -3 %, 12: -4 %)
+#define R1_NODES_LDS_MAX 256  // tree kernel: scenes whose tree has at most this many nodes (16 KB) run the small-scene kernels, which keep
+                              // the node table in LDS; bigger trees run the big-scene kernels (node table through the vector L1)
 #define R1_CHUNK 256        // most samples a wave takes from the global queue per atomic (small frames) ...
 #define R1_CHUNK_BIG 1024   // ... growing with a wave's share of the frame up to this (enqueue_frame)
 #define R1_CHUNK_MIN 32      // fewest (end of the queue: guided self-scheduling)
@@ -61,14 +66,15 @@ struct R1DeviceScene
     uint32_t n_active;     // real entries
     uint32_t n_sweep;      // GROUPS, padded to a multiple of 8 (+8 prefetch); big scenes: of R1_TILE_SPHERES (+ one tile)
     // R1_VARIANT_BVH (r1_bvh.cpp): binary tree of boxes over the active spheres.  Node = 4 float4:
-    // {m0x m1x m0y m1y} {m0z m1z e0x e1x} {e0y e1y e0z e1z} {w2 k child0 child1}; child i has
-    // centre m_i and half extent e_i, inflated per ray by pad = w2 |m_i - o|^2 + k.  Child
+    // {m0x m1x m0y m1y} {m0z m1z e0x e1x} {e0y e1y e0z e1z} {A K child0 child1}; child i has
+    // centre m_i and half extent e_i, inflated per ray by pad = A |o - bvh_centre|^2 + K.  Child
     // reference: bit 31 clear = inner node index; set = leaf, bits 28..30 number of sphere PAIRS,
     // bits 0..27 first pair of bvh_prims (2 float4 per pair {cx_a cx_b cy_a cy_b} {cz_a cz_b rsq_a
     // rsq_b}) / bvh_ids (2 active indices per pair).  Node 0 is the root.
     const float4 *bvh_nodes;
     const float4 *bvh_prims;
     const uint32_t *bvh_ids;
+    float bvh_centre[3];
 };
 
 struct R1DeviceCamera
@@ -106,6 +112,7 @@ struct R1TraceArgs
     unsigned long long *num_rays; // accumulated color() invocations
     uint32_t *gstack;             // big scenes: attenuation stack [R1_STACK_ENTRIES][grid threads], else null
     unsigned long long *stats;    // diagnostic counters (R1_VARIANT_STATS builds only), else null
+    uint32_t bvh_lds_f4;          // tree kernels: float4 of the node table each workgroup copies into LDS behind the traversal stack (0: none)
     int32_t bvh_depth;            // tree kernels: traversal stack entries per thread (dynamic LDS = depth * R1_BLOCK * 4)
     int32_t block_layout;         // PIXEL mode: 1 = `samples` is a dense tile block (pixel index = queue slot), 0 = a row-major image
     float inv_spp;                // PIXEL mode: (float)(1.0f / spp), rayweek1.cpp:765

@@ -585,7 +585,7 @@ __device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const bo
 // ---- sweep through the optional spatial index (R1_VARIANT_BVH) -------------
 // Per-lane ordered traversal of the binary box tree built by r1_bvh.cpp.  Only the choice of
 // spheres presented to exact_offer differs from the exhaustive sweeps; the boxes are inflated
-// by pad = w2 |m - o|^2 + k (conservative with respect to the reference's fp32 test, see
+// by pad = A |o - C|^2 + K (conservative with respect to the reference's fp32 test, see
 // r1_bvh.cpp) and a subtree is skipped only if its inflated box is missed or lies entirely
 // beyond the closest offer so far.  Result = minimum offer, ties to the lowest sphere index —
 // the reference's in-order rule (see exact_offer).  The traversal stack lives in LDS,
@@ -594,19 +594,19 @@ __device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const bo
 
 // STATS (diagnostic build): wstat[2] wave trips of the node loop, [3] wave trips of the leaf
 // pair loop, [9] node visits summed over lanes, [5] sphere-pair tests summed over lanes.
-// One child box {m, e} inflated by pad = w2 |m - o|^2 + k against the ray.  Scalar arithmetic on
-// purpose: the packed form (both children per v_pk_* instruction) costs the same issue cycles on
-// this chip (profiles/r01/isa_issue_costs.txt) but 13 more VGPRs, and the kernel's register count
-// sits right at the limit for 6 waves per SIMD.
+// One child box {m, e} against the ray, inflated by the node's pad (pa = pad * |1/d| per axis, computed once
+// per node visit for both children; pad = A |o - C|^2 + K, conservative with respect to the reference's fp32
+// sphere test AND to this test's own rounding: r1_bvh.cpp).  Slab form a = m / d - o / d (one fused
+// multiply-add per axis, oi = o * (1/d) rounded once per ray), b = e |1/d| + pa: 17 VALU instructions per
+// box against 28 for the round-1 form that measured |m - o|^2 per box.  Scalar arithmetic on purpose: the
+// packed form (both children per v_pk_* instruction) costs the same issue cycles on this chip
+// (profiles/r01/isa_issue_costs.txt) but more VGPRs.
 __device__ __forceinline__ bool bvh_box(const float mx, const float my, const float mz, const float ex, const float ey, const float ez,
-                                        const float w2, const float k, const V3 o, const V3 inv, const V3 ainv, const float best, float &t_near)
+                                        const V3 pa, const V3 oi, const V3 inv, const V3 ainv, const float best, float &t_near)
 {
-    const float cx = mx - o.x, cy = my - o.y, cz = mz - o.z;
-    const float d2 = __fmaf_rn(cz, cz, __fmaf_rn(cy, cy, cx * cx));
-    const float pad = __fmaf_rn(w2, d2, k);
-    const float ax = cx * inv.x, ay = cy * inv.y, az = cz * inv.z;
-    const float bx = (ex + pad) * ainv.x, by = (ey + pad) * ainv.y, bz = (ez + pad) * ainv.z;
-    // NaN (0 x inf on an axis the ray does not move along) drops out of fmaxf/fminf: no constraint
+    const float ax = __fmaf_rn(mx, inv.x, -oi.x), ay = __fmaf_rn(my, inv.y, -oi.y), az = __fmaf_rn(mz, inv.z, -oi.z);
+    const float bx = __fmaf_rn(ex, ainv.x, pa.x), by = __fmaf_rn(ey, ainv.y, pa.y), bz = __fmaf_rn(ez, ainv.z, pa.z);
+    // NaN (an axis the ray does not move along: inf - inf, 0 x inf) drops out of fmaxf/fminf: no constraint
     const float tn = fmaxf(fmaxf(ax - bx, ay - by), az - bz);
     const float tf = fminf(fminf(ax + bx, ay + by), az + bz);
     t_near = tn;
@@ -694,17 +694,21 @@ __device__ __forceinline__ void trav_start(Trav &t)
 // Measured on the large scene (tools/bvh_stats.py): lane utilisation of the node / leaf steps 0.48 / 0.58 ->
 // 0.70 / 0.65, a third fewer trips — and +1.5 % frames in flight, -2 % for one synchronous frame, because the vote costs
 // ~20 VALU instructions per trip in a kernel that is bound by its VALU instruction count.
-template <bool STATS, bool CARRY, bool MAJORITY>
+// LN: the node table is read from `lnodes`, the workgroup's copy in LDS (the trace kernel on small scenes), instead of S.bvh_nodes.
+template <bool STATS, bool CARRY, bool MAJORITY, bool LN>
 __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, const V3 d, Trav &tv, uint32_t *trav, const int tid,
-                                            const uint32_t n_alive, unsigned long long *wstat)
+                                            const uint32_t n_alive, unsigned long long *wstat, const float4 *lnodes /* LDS */)
 {
     const float4 *__restrict__ nodes = S.bvh_nodes;
     const float4 *__restrict__ prims = S.bvh_prims;
     const uint32_t *__restrict__ ids = S.bvh_ids;
     // v_rcp_f32 (1 ulp) is enough here: the reciprocals only feed the conservative box test, whose
-    // pad budgets 2^-19 (|m - o|^2 + h^2) + 2^-20 for its own rounding (r1_bvh.cpp)
+    // pad budgets for its own rounding (r1_bvh.cpp)
     const V3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
     const V3 ainv = mk(fabsf(inv.x), fabsf(inv.y), fabsf(inv.z));
+    const V3 oi = mk(o.x * inv.x, o.y * inv.y, o.z * inv.z);
+    const float rx = o.x - S.bvh_centre[0], ry = o.y - S.bvh_centre[1], rz = o.z - S.bvh_centre[2];
+    const float r2 = __fmaf_rn(rz, rz, __fmaf_rn(ry, ry, rx * rx)); // |o - C|^2 of pad = A r2 + K
     float best = tv.best;
     uint32_t best_id = tv.best_id;
     uint32_t cur = tv.cur;
@@ -731,11 +735,17 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
                     if ((tid & 63) == __ffsll((long long)__ballot(1)) - 1)
                         wstat[2] += 1;
                 }
-                const float4 q0 = nodes[4 * (size_t)cur + 0], q1 = nodes[4 * (size_t)cur + 1], q2 = nodes[4 * (size_t)cur + 2],
-                             q3 = nodes[4 * (size_t)cur + 3];
+                float4 q0, q1, q2, q3;
+                if (LN)
+                    q0 = lnodes[4 * cur + 0], q1 = lnodes[4 * cur + 1], q2 = lnodes[4 * cur + 2], q3 = lnodes[4 * cur + 3];
+                else
+                    q0 = nodes[4 * (size_t)cur + 0], q1 = nodes[4 * (size_t)cur + 1], q2 = nodes[4 * (size_t)cur + 2],
+                    q3 = nodes[4 * (size_t)cur + 3];
                 float tn0, tn1;
-                const bool h0 = bvh_box(q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, q3.x, q3.y, o, inv, ainv, best, tn0);
-                const bool h1 = bvh_box(q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, q3.x, q3.y, o, inv, ainv, best, tn1);
+                const float pad = __fmaf_rn(q3.x, r2, q3.y);
+                const V3 pa = mk(pad * ainv.x, pad * ainv.y, pad * ainv.z);
+                const bool h0 = bvh_box(q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, pa, oi, inv, ainv, best, tn0);
+                const bool h1 = bvh_box(q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, pa, oi, inv, ainv, best, tn1);
                 const uint32_t c0 = __float_as_uint(q3.z), c1 = __float_as_uint(q3.w);
                 if (h0 && h1)
                 {
@@ -783,12 +793,18 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
                 if ((tid & 63) == __ffsll((long long)__ballot(1)) - 1)
                     wstat[2] += 1;
             }
-            // {m0x m1x m0y m1y} {m0z m1z e0x e1x} {e0y e1y e0z e1z} {w2 k child0 child1}
-            const float4 q0 = nodes[4 * (size_t)cur + 0], q1 = nodes[4 * (size_t)cur + 1], q2 = nodes[4 * (size_t)cur + 2],
-                         q3 = nodes[4 * (size_t)cur + 3];
+            // {m0x m1x m0y m1y} {m0z m1z e0x e1x} {e0y e1y e0z e1z} {A K child0 child1}
+            float4 q0, q1, q2, q3;
+            if (LN)
+                q0 = lnodes[4 * cur + 0], q1 = lnodes[4 * cur + 1], q2 = lnodes[4 * cur + 2], q3 = lnodes[4 * cur + 3];
+            else
+                q0 = nodes[4 * (size_t)cur + 0], q1 = nodes[4 * (size_t)cur + 1], q2 = nodes[4 * (size_t)cur + 2],
+                q3 = nodes[4 * (size_t)cur + 3];
             float tn0, tn1;
-            const bool h0 = bvh_box(q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, q3.x, q3.y, o, inv, ainv, best, tn0);
-            const bool h1 = bvh_box(q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, q3.x, q3.y, o, inv, ainv, best, tn1);
+            const float pad = __fmaf_rn(q3.x, r2, q3.y);
+            const V3 pa = mk(pad * ainv.x, pad * ainv.y, pad * ainv.z);
+            const bool h0 = bvh_box(q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, pa, oi, inv, ainv, best, tn0);
+            const bool h1 = bvh_box(q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, pa, oi, inv, ainv, best, tn1);
             const uint32_t c0 = __float_as_uint(q3.z), c1 = __float_as_uint(q3.w);
             if (h0 && h1)
             {
@@ -837,7 +853,7 @@ __device__ __forceinline__ void sweep_bvh(const R1DeviceScene &S, const bool ali
     trav_start(tv);
     if (!alive)
         tv.cur = R1_BVH_DONE;
-    bvh_advance<STATS, false, false>(S, o, d, tv, trav, tid, 64u, wstat);
+    bvh_advance<STATS, false, false, false>(S, o, d, tv, trav, tid, 64u, wstat, nullptr);
     if (tv.best_id != 0xFFFFFFFFu)
     {
         t_max = tv.best;
@@ -894,12 +910,17 @@ __device__ __forceinline__ void cooperative_sweep(const R1DeviceScene &S, unsign
 // Attenuation stack.  Small scenes: packed in LDS, three 10-bit sphere indices per word.  Big
 // scenes (> 1023 active spheres): one u32 per entry in a global workspace laid out
 // [entry][global thread] (coalesced); its traffic is nothing next to a 100 k-sphere sweep.
-template <bool BIG>
+template <bool BIG, int LW = R1_STACK_WORDS>
 __device__ __forceinline__ void stack_push(uint32_t *stack, uint32_t *gstack, uint32_t gstride, uint32_t gtid, int tid, int sp, uint32_t idx)
 {
     if (BIG)
     {
         gstack[(size_t)sp * gstride + gtid] = idx;
+        return;
+    }
+    if (LW < R1_STACK_WORDS && sp >= 3 * LW) // deep entries (rare): global workspace, [entry - 3 LW][global thread]
+    {
+        gstack[(size_t)(sp - 3 * LW) * gstride + gtid] = idx;
         return;
     }
     const int w = sp / 3, sh = (sp - 3 * w) * 10;
@@ -1052,7 +1073,7 @@ __device__ __forceinline__ bool path_load(const float4 *paths, const uint32_t n,
 // scatter (new ray in p, hit index pushed on the attenuation stack) or finish the path: sky
 // colour times the stacked attenuations, or black.  Returns true when the path has ended, with
 // its radiance in `col`.  Shared by the megakernel and the wavefront kernels.
-template <bool BIG>
+template <bool BIG, int LW = R1_STACK_WORDS>
 __device__ __forceinline__ bool shade_level(const R1TraceArgs &A, Path &p, const int hit, const float t_hit, uint32_t *s_stack,
                                             const uint32_t gstride, const uint32_t gtid, const int tid, V3 &col)
 {
@@ -1129,7 +1150,7 @@ __device__ __forceinline__ bool shade_level(const R1TraceArgs &A, Path &p, const
             {
                 if (type != 2u)
                 {
-                    stack_push<BIG>(s_stack, A.gstack, gstride, gtid, tid, p.sp, (uint32_t)hit);
+                    stack_push<BIG, LW>(s_stack, A.gstack, gstride, gtid, tid, p.sp, (uint32_t)hit);
                     ++p.sp;
                 }
             }
@@ -1157,9 +1178,19 @@ __device__ __forceinline__ bool shade_level(const R1TraceArgs &A, Path &p, const
         }
         else if (p.sp > 0)
         {
+            int top = p.sp;
+            if (LW < R1_STACK_WORDS)
+            {
+                for (int e = top - 1; e >= 3 * LW; --e) // the deep entries first (innermost attenuation first)
+                {
+                    const float4 sh = A.scene.shade[A.gstack[(size_t)(e - 3 * LW) * gstride + gtid]];
+                    col = mk(sh.y * col.x, sh.z * col.y, sh.w * col.z);
+                }
+                top = top < 3 * LW ? top : 3 * LW;
+            }
             // packed stack: one LDS word holds entries 3w, 3w+1, 3w+2 (10 bits each); walk it word by
             // word from the top entry down instead of dividing every entry index by 3
-            int w = (p.sp - 1) / 3, j = (p.sp - 1) - 3 * w;
+            int w = (top - 1) / 3, j = (top - 1) - 3 * w;
             for (; w >= 0; --w, j = 2)
             {
                 const uint32_t v = s_stack[w * R1_BLOCK + tid];
@@ -1191,8 +1222,8 @@ __device__ __forceinline__ bool shade_level(const R1TraceArgs &A, Path &p, const
 // STATS = diagnostic build (variant R1_VARIANT_STATS): same results, plus per-phase cycle and
 // utilisation counters in A.stats; never used by the product path.
 // Waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument): the
-// product kernels are sized by their LDS (tree: 6 workgroups per CU, exhaustive sweep: 5), so their VGPR
-// count has to stay under 512 / 6 -> 80 and 512 / 5 -> 96.
+// product kernels are sized by their LDS (tree: 6 workgroups per CU with a 128-node table — 8 KB attenuation stack + 8 KB
+// traversal stack + 8 KB nodes; exhaustive sweep: 5), so their VGPR count has to stay under 512 / 6 -> 80 and 512 / 5 -> 96.
 template <int VARIANT, bool STATS, bool BIG>
 struct TraceWaves
 {
@@ -1225,7 +1256,8 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
         wave_log = (unsigned long long *)A.stats[15];
         log_start = __builtin_amdgcn_s_memrealtime();
     }
-    __shared__ uint32_t s_stack[BIG ? 1 : R1_STACK_WORDS * R1_BLOCK];
+    constexpr int LW = VARIANT == 4 ? R1_STACK_LDS_WORDS : R1_STACK_WORDS; // words of the attenuation stack in LDS
+    __shared__ uint32_t s_stack[BIG ? 1 : LW * R1_BLOCK];
     __shared__ uint32_t s_cand[VARIANT == 2 ? (BIG ? R1_CAND_CAP : R1_BIT_WORDS) * R1_BLOCK : 1];
     __shared__ IDX s_pairs[VARIANT == 2 ? (R1_BLOCK / 64) * PairBits<IDX>::cap : 1];
     // R1_VARIANT_BVH: traversal stack [tree depth][thread], sized at launch (dynamic LDS)
@@ -1236,6 +1268,20 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
+
+    // Tree kernels, small scenes (!BIG: at most R1_NODES_LDS_MAX nodes, r1_capi.cpp): the workgroup keeps its own copy of
+    // the node table in LDS, behind the traversal stack.  A node visit is four dependent 16-byte loads per lane; LDS
+    // answers sooner than the vector L1, and the table no longer competes with the sphere tables for its 32 KB:
+    // 26.9 -> 29.3 Grays/s, one synchronous frame 1.34 -> 1.17 ms (large scene, 128 nodes = 8 KB).
+    constexpr bool LN = VARIANT == 4 && !BIG;
+    const float4 *lnodes = (const float4 *)(s_trav + (LN ? (size_t)A.bvh_depth * R1_BLOCK : 0));
+    if (LN)
+    {
+        float4 *dst = (float4 *)(s_trav + (size_t)A.bvh_depth * R1_BLOCK);
+        for (uint32_t i = (uint32_t)tid; i < A.bvh_lds_f4; i += R1_BLOCK)
+            dst[i] = A.scene.bvh_nodes[i];
+        __syncthreads();
+    }
 
     Path p;
     p.o = mk(0, 0, 0), p.d = mk(0, 0, 0);
@@ -1383,7 +1429,7 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
         {
             // frames in flight (and the diagnostic build, whose counts go with that line): one step per trip by
             // majority; a synchronous frame: while-while.  Both carry unfinished walks over.
-            bvh_advance<STATS, true, (STATS || !LAT)>(A.scene, p.o, p.d, tv, s_trav, tid, (uint32_t)__popcll(live_now), wstat);
+            bvh_advance<STATS, true, (STATS || !LAT), LN>(A.scene, p.o, p.d, tv, s_trav, tid, (uint32_t)__popcll(live_now), wstat, lnodes);
             ready = alive && tv.cur == R1_BVH_DONE;
             if (tv.best_id != 0xFFFFFFFFu)
                 t_hit = tv.best, hit = (int)tv.best_id;
@@ -1399,7 +1445,7 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
         if (ready)
         {
             V3 col;
-            if (shade_level<BIG>(A, p, hit, t_hit, s_stack, gstride, gtid, tid, col))
+            if (shade_level<BIG, LW>(A, p, hit, t_hit, s_stack, gstride, gtid, tid, col))
             {
                 if (PIX)
                 {
@@ -1653,8 +1699,8 @@ extern "C" int r1_trace_mode(int variant, int big, int wanted)
 
 extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int big_in, int mode, int blocks, hipStream_t stream)
 {
-    // dynamic LDS: the traversal stack of the tree kernels, one entry per inner node on a path
-    const size_t trav = (variant == 4 || variant == 5) ? (size_t)args->bvh_depth * R1_BLOCK * sizeof(uint32_t) : 0;
+    // dynamic LDS of the tree kernels: the traversal stack, one entry per inner node on a path, and (small scenes) the node table
+    const size_t trav = ((variant == 4 || variant == 5) ? (size_t)args->bvh_depth * R1_BLOCK * sizeof(uint32_t) + (size_t)args->bvh_lds_f4 * 16 : 0);
     const bool big = big_in != 0; // 32-bit hit indices, attenuation stack in the global workspace
 #define R1_GO(V, S, B, M) hipLaunchKernelGGL((r1_trace_kernel<V, S, B, M>), dim3(blocks), dim3(R1_BLOCK), (V) == 4 ? trav : 0, stream, *args)
     if (mode != r1_trace_mode(variant, big_in, mode))

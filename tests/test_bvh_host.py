@@ -108,28 +108,34 @@ def ref_flagged(cx, cy, cz, rsq, o, d):
     return ok & ((t1 > F(0.001)) | (t2 > F(0.001)))
 
 
-def traverse(nodes, o, d, jitter=None):
-    """The kernel's visit rule without distance pruning: leaf slots the ray is shown."""
+def traverse(nodes, centre, o, d, jitter=None):
+    """The kernel's visit rule (r1_kernels.hip::bvh_box, fp32 step by step) without distance pruning: leaf slots the ray is shown."""
     o = o.astype(F)
-    with np.errstate(divide="ignore", invalid="ignore"):
+
+    def fma(a, b, c):  # exactly rounded fp32 fma (the product of two fp32 is exact in fp64; inf/NaN propagate alike)
+        return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(F)
+
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
         inv = (F(1) / d.astype(F)).astype(F)
         if jitter is not None:  # the kernel uses v_rcp_f32 (1 ulp): any reciprocal within one ulp must do
             inv = np.where(np.isfinite(inv), np.nextafter(inv, np.where(jitter > 0, F(np.inf), F(-np.inf)).astype(F)), inv).astype(F)
+        ainv = np.abs(inv)
+        oi = (o * inv).astype(F)
+        r = (o - centre.astype(F)).astype(F)
+        r2 = fma(r[2], r[2], fma(r[1], r[1], F(r[0] * r[0])))
         out = []
         stack = [0]
         while stack:
             n = stack.pop()
             row = nodes[n]
             refs = row.view(np.uint32)
-            w2, k = row[12], row[13]
+            pad = fma(row[12], r2, row[13])
+            pa = (pad * ainv).astype(F)
             for c in (0, 1):
-                com = (row[list(M[c])] - o).astype(F)
-                d2 = F(com[2] * com[2] + F(com[1] * com[1] + F(com[0] * com[0])))
-                pad = F(w2 * d2 + k)
-                a = (com * inv).astype(F)
-                b = ((row[list(E[c])] + pad).astype(F) * np.abs(inv)).astype(F)
-                tn = np.fmax(np.fmax(a[0] - b[0], a[1] - b[1]), a[2] - b[2])
-                tf = np.fmin(np.fmin(a[0] + b[0], a[1] + b[1]), a[2] + b[2])
+                a = fma(row[list(M[c])], inv, -oi)
+                b = fma(row[list(E[c])], ainv, pa)
+                tn = np.fmax(np.fmax(F(a[0] - b[0]), F(a[1] - b[1])), F(a[2] - b[2]))
+                tf = np.fmin(np.fmin(F(a[0] + b[0]), F(a[1] + b[1])), F(a[2] + b[2]))
                 if tn <= tf and tf >= 0:
                     ref = int(refs[REF[c]])
                     if ref & LEAF:
@@ -167,7 +173,7 @@ def test_traversal_rule_presents_every_sphere_the_reference_flags(kind):
         if q % 7 == 0:
             d = np.array([0, 0, -1], F) if q % 2 else np.array([1, 0, 0], F)  # axis-parallel: infinite reciprocals
         flagged = set(np.nonzero(ref_flagged(cx, cy, cz, rsq, o, d) & active)[0].tolist())
-        shown = set(ids[traverse(nodes, o, d, rng.integers(0, 2, 3) * 2 - 1)].tolist()) - {EMPTY}
+        shown = set(ids[traverse(nodes, info["centre"], o, d, rng.integers(0, 2, 3) * 2 - 1)].tolist()) - {EMPTY}
         assert flagged <= shown, (q, sorted(flagged - shown)[:5])
         shown_total += len(shown)
         flagged_total += len(flagged)
@@ -220,7 +226,7 @@ def test_random_scenes_tree_invariants_and_visit_rule(seed):
         d = (target - o).astype(np.float64)
         d = (d / np.linalg.norm(d)).astype(F)
         flagged = set(np.nonzero(ref_flagged(cx, cy, cz, rsq, o, d))[0].tolist())
-        shown = set(ids[traverse(nodes, o, d, rng.integers(0, 2, 3) * 2 - 1)].tolist()) - {EMPTY}
+        shown = set(ids[traverse(nodes, info["centre"], o, d, rng.integers(0, 2, 3) * 2 - 1)].tolist()) - {EMPTY}
         assert flagged <= shown, (seed, q, sorted(flagged - shown)[:5])
 
 
@@ -294,7 +300,7 @@ def test_visit_rule_on_adversarial_families(family):
         d = target - o.astype(np.float64)
         d = (d / np.linalg.norm(d)).astype(F)
         flagged = set(np.nonzero(ref_flagged(cx, cy, cz, rsq, o, d))[0].tolist())
-        shown = set(ids[traverse(nodes, o, d, rng.integers(0, 2, 3) * 2 - 1)].tolist()) - {EMPTY}
+        shown = set(ids[traverse(nodes, info["centre"], o, d, rng.integers(0, 2, 3) * 2 - 1)].tolist()) - {EMPTY}
         assert flagged <= shown, (family, q, sorted(flagged - shown)[:5])
         hits += len(flagged)
     assert hits > 0  # the family does produce reference candidates (for degenerate radii: rounding-noise hits)

@@ -105,7 +105,7 @@ def test_bvh_equals_exhaustive_sweep_at_the_baseline_size(renderer, name):
     assert same(a, b)
 
 
-@pytest.mark.parametrize("n_active", [0, 1, 2, 4, 5, 9, 1023, 1024])
+@pytest.mark.parametrize("n_active", [0, 1, 2, 4, 5, 9, 600, 1023, 1024])
 def test_bvh_sphere_count_edges(renderer, n_active):
     w, h, spp = 64, 48, 2
     src = r1.create_grid_scene(w, h, 36, 30)
@@ -115,6 +115,10 @@ def test_bvh_sphere_count_edges(renderer, n_active):
     sa = r1o.SceneArrays(sub, src.camera_array())
     renderer.set_scene_raw(_as_cscene(sa), _as_ccamera(sa))
     got = renderer.render_samples(r1.make_params(w, h, spp, 9, variant=BVH))
+    # 600 spheres: a node table of more than 128 but at most 256 nodes, kept in LDS by the small-scene kernels;
+    # 1023: more than 256 nodes, so the big-scene tree kernels run although the hit indices would fit 10 bits
+    nodes = renderer.launch_info()["bvh_nodes"]
+    assert {600: 128 < nodes <= 256, 1023: nodes > 256}.get(n_active, True), nodes
     ref = renderer.render_samples(r1.make_params(w, h, spp, 9, variant=binding.VARIANT_REFERENCE))
     assert same(got, ref)
     oimg, orays, osamples = r1o.render_frame(sa, oparams(r1.make_params(w, h, spp, 9)), want_samples=True)
@@ -172,6 +176,36 @@ def test_bvh_is_exact_on_adversarial_scenes(renderer, case):
     assert same(got, ref)
     oimg, orays, osamples = r1o.render_frame(sa, oparams(r1.make_params(w, h, spp, 1234)), want_samples=True)
     assert got[1] == orays and got[2].tobytes() == osamples.tobytes()
+
+
+def test_bvh_deep_paths_between_two_huge_spheres(renderer):
+    """A gap of two units between a floor and a ceiling sphere of radius 1000, bright Lambertian: paths bounce dozens of
+    times before they escape sideways to the sky, so the attenuation stack runs past the 24 entries the tree kernel
+    keeps in LDS (R1_STACK_LDS_WORDS; deeper entries live in the global workspace) and is unwound from there with a
+    non-zero sky colour.  Bit-identical to the reference-form kernel (whole stack in LDS) and to the oracle."""
+    rng = np.random.default_rng(77)
+    w, h, spp = 64, 40, 4
+    n = 140
+    c = np.concatenate([[[0.0, -1001.0, 0.0], [0.0, 1001.0, 0.0]], rng.uniform(-6, 6, (n - 2, 3)) * np.array([1.0, 0.12, 1.0])])
+    rad = np.concatenate([[1000.0, 1000.0], rng.uniform(0.05, 0.25, n - 2)])
+    arr = spheres(c, rad, rng)
+    arr["mat_type"][:2] = 0
+    for k, v in (("albedo_r", 0.97), ("albedo_g", 0.93), ("albedo_b", 0.9)):
+        arr[k][:2] = v
+    cam = r1.create_small_scene(w, h).camera_array().copy()
+    cam[0:3] = (0.0, 0.0, 3.0)                       # origin in the middle of the gap
+    cam[3:6] = (-2.0, -1.25, 3.0 - 2.0)              # lower_left
+    cam[6:9], cam[9:12] = (4.0, 0.0, 0.0), (0.0, 2.5, 0.0)
+    sa = r1o.SceneArrays(arr, cam)
+    renderer.set_scene_raw(_as_cscene(sa), _as_ccamera(sa))
+    got = renderer.render_samples(r1.make_params(w, h, spp, 31, variant=BVH))
+    ref = renderer.render_samples(r1.make_params(w, h, spp, 31, variant=binding.VARIANT_REFERENCE))
+    assert same(got, ref)
+    oimg, orays, osamples = r1o.render_frame(sa, oparams(r1.make_params(w, h, spp, 31)), want_samples=True)
+    assert got[1] == orays and got[2].tobytes() == osamples.tobytes()
+    n_rays = got[2][:, 3].copy().view(np.uint32)
+    deep_and_lit = (n_rays > 30) & (n_rays < 51) & (got[2][:, :3].sum(1) > 0)
+    assert deep_and_lit.sum() > 20, int(deep_and_lit.sum())  # the deep entries are really unwound with colour
 
 
 def test_bvh_axis_parallel_rays(renderer):
