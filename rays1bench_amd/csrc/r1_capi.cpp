@@ -440,7 +440,8 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
 
     // sweep table: pair layout + one chunk of prefetch padding (see r1_device.h)
     const uint32_t ns_alloc = ns + (big_scene ? R1_TILE_SPHERES : 8);
-    std::vector<float> sweep(4 * (size_t)ns_alloc), exact(4 * (size_t)(na ? na : 1)), shade(4 * (size_t)(na ? na : 1)),
+    std::vector<float> sweep(4 * (size_t)ns_alloc), exact(4 * (size_t)(na ? na : 1)),
+        shade(4 * (size_t)(na > R1_MAX_ACTIVE_10BIT ? na : R1_MAX_ACTIVE_10BIT + 1)), // small scenes: any 10-bit index may be read (unwind)
         mat(4 * (size_t)(na ? na : 1));
     std::vector<uint32_t> members((size_t)R1_GROUP_MAX * ns_alloc, 0xFFFFFFFFu);
     auto sweep_slot = [&](uint32_t a, int comp) -> float & { return sweep[8 * (size_t)(a >> 1) + 2 * comp + (a & 1)]; };
@@ -787,7 +788,10 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     }
     if (big || (R1_STACK_LDS_WORDS < R1_STACK_WORDS && (variant == 4 || variant == 5)))
     {
-        if ((rc = ensure(c->gstack, (size_t)R1_STACK_ENTRIES * (size_t)blocks * R1_BLOCK * 4)))
+        // sized for the largest grid of this kernel (not this frame's): a frame with a bigger grid must not reallocate
+        const size_t entries = big ? R1_STACK_ENTRIES : R1_STACK_ENTRIES - 3 * R1_STACK_LDS_WORDS;
+        const size_t max_blocks = std::max((size_t)blocks, (size_t)c->cus * (size_t)per_cu);
+        if ((rc = ensure(c->gstack, entries * max_blocks * R1_BLOCK * 4)))
             return rc;
         a.gstack = (uint32_t *)c->gstack.p;
     }

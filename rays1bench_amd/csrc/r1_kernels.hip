@@ -1188,24 +1188,19 @@ __device__ __forceinline__ bool shade_level(const R1TraceArgs &A, Path &p, const
                 }
                 top = top < 3 * LW ? top : 3 * LW;
             }
-            // packed stack: one LDS word holds entries 3w, 3w+1, 3w+2 (10 bits each); walk it word by
-            // word from the top entry down instead of dividing every entry index by 3
+            // packed stack: one LDS word holds entries 3w, 3w+1, 3w+2 (10 bits each); walk it word by word from the top
+            // entry down.  The three albedos of a word are fetched together, whether the word is full or not (any 10-bit
+            // index is inside the table, r1_capi.cpp), and the slots above the top entry multiply by 1.0f, which changes
+            // no bit: one round trip to the table per word instead of one per entry.
             int w = (top - 1) / 3, j = (top - 1) - 3 * w;
             for (; w >= 0; --w, j = 2)
             {
                 const uint32_t v = s_stack[w * R1_BLOCK + tid];
-                if (j >= 2)
-                {
-                    const float4 sh = A.scene.shade[(v >> 20) & 0x3FFu];
-                    col = mk(sh.y * col.x, sh.z * col.y, sh.w * col.z);
-                }
-                if (j >= 1)
-                {
-                    const float4 sh = A.scene.shade[(v >> 10) & 0x3FFu];
-                    col = mk(sh.y * col.x, sh.z * col.y, sh.w * col.z);
-                }
-                const float4 sh = A.scene.shade[v & 0x3FFu];
-                col = mk(sh.y * col.x, sh.z * col.y, sh.w * col.z);
+                const float4 s2 = A.scene.shade[(v >> 20) & 0x3FFu], s1 = A.scene.shade[(v >> 10) & 0x3FFu], s0 = A.scene.shade[v & 0x3FFu];
+                const bool u2 = j >= 2, u1 = j >= 1;
+                col = mk((u2 ? s2.y : 1.0f) * col.x, (u2 ? s2.z : 1.0f) * col.y, (u2 ? s2.w : 1.0f) * col.z);
+                col = mk((u1 ? s1.y : 1.0f) * col.x, (u1 ? s1.z : 1.0f) * col.y, (u1 ? s1.w : 1.0f) * col.z);
+                col = mk(s0.y * col.x, s0.z * col.y, s0.w * col.z);
             }
         }
         done = true;

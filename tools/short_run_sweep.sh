@@ -9,6 +9,6 @@ run() {
   echo -n " | 300 steps: "
   env $1 python bench.py --gpus 1 --steps 300 --warmup 20 --no-cpu-baseline --inflight $2 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.0f  wg %d' % (d['value'], d['config']['workgroups']))"
 }
-for inflight in 8 12 16; do for spl in 60 100 150; do
-  run "R1_SAMPLES_PER_LANE=$spl" $inflight
-done; done
+for cfg in ${SWEEP:-"16 150" "16 122" "16 100" "16 75" "16 61" "16 50" "20 122" "20 100" "10 122" "12 100"}; do set -- $cfg
+  run "R1_SAMPLES_PER_LANE=$2" $1
+done
