@@ -136,10 +136,11 @@ def cpu_baseline_grid(sc, w, h):
 
 
 # flop per unit of the hit tests, counted from r1_kernels.hip (add / mul / compare / min / max = 1, fma = 2):
-#   bvh_box      3 sub, |m-o|^2 (mul + 2 fma), pad fma, 3 mul, 3 add + 3 mul, 3 sub + 2 max, 3 add + 2 min, min + 2 cmp  = 32
+#   node visit   pad fma + 3 mul once, then per child box (bvh_box): 3 fma, 3 fma, 3 sub + 2 max, 3 add + 2 min, min + 2 cmp = 25
+#                -> 5 + 2 x 25 = 55 (the round-1 form, which measured |m - o|^2 per box, was 2 x 32)
 #   exact_offer  pass 1 of Hitable::hit for one sphere = SURVEY.md §8d's 16 flop (3 sub, mul + 2 fma, mul + 2 fma, sub, mul + sub)
 #   group test   7 fma + 1 sub of the prefilter (sweep_prefilter)                                                       = 15
-FLOP_BOX, FLOP_SPHERE, FLOP_GROUP = 32.0, 16.0, 15.0
+FLOP_NODE, FLOP_SPHERE, FLOP_GROUP = 55.0, 16.0, 15.0
 
 
 def measure_work(rend, p, info, binding):
@@ -159,8 +160,8 @@ def measure_work(rend, p, info, binding):
         visits, pairs, leaf_lane_trips = st["candidates"], st["cycles_pass1"] & 0xFFFFFFFF, st["cycles_pass1"] >> 32
         return {"source": "R1_VARIANT_BVH_STATS frame (same samples as the timed kernel)", "rays_per_launch": rays,
                 "node_visits_per_ray": visits / rays, "sphere_pair_tests_per_ray": pairs / rays,
-                "flop_per_node_visit": 2 * FLOP_BOX, "flop_per_sphere_pair_test": 2 * FLOP_SPHERE,
-                "flop_per_launch": visits * 2 * FLOP_BOX + pairs * 2 * FLOP_SPHERE,
+                "flop_per_node_visit": FLOP_NODE, "flop_per_sphere_pair_test": 2 * FLOP_SPHERE,
+                "flop_per_launch": visits * FLOP_NODE + pairs * 2 * FLOP_SPHERE,
                 "lane_utilisation": {"at_hit_test": st["alive_lanes"] / (64.0 * it),
                                      "node_loop": visits / (64.0 * max(st["candidate_loop_trips"], 1)),
                                      "leaf_loop": leaf_lane_trips / (64.0 * max(st["overflow_lanes"], 1))}}
@@ -185,9 +186,10 @@ def main():
     ap.add_argument("--grid", default="400x250", help="with --scene grid: small-sphere lattice WxH (BASELINE config 5: 400x250)")
     ap.add_argument("--seed", type=int, default=10001)
     ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--inflight", type=int, default=16,
+    ap.add_argument("--inflight", type=int, default=0,
                     help="frames in flight, each on its own stream + context workspace: later frames' workgroups fill "
-                         "the CUs that a frame's last long bounce chains leave idle (1 = one frame at a time)")
+                         "the CUs that a frame's last long bounce chains leave idle (1 = one frame at a time; "
+                         "0 = default: 20 on one GPU, 16 per rank when RCCL needs hardware queues of its own)")
     ap.add_argument("--emulate-shards", type=int, default=0,
                     help="tuning aid: render only shard 0 of K on one GPU, no collective (per-rank load of a K-GPU run)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
@@ -206,6 +208,10 @@ def main():
     # per-rank frame time at 1/2/4 and 8 shards, 4 queues 78 % / 66 %).  Must be set before HIP starts.
     # One queue per frame in flight: streams that share a queue serialise, and spare queues hurt too
     # (measured: 16 in flight on 16 queues 1.18 ms per frame; 12 on 16: 1.77; 12 on 12: 1.20; 24 on 24: 1.53).
+    # 20 in flight on 20 queues: the driver's short run (20 steps) 26.3 -> 27.1 Grays/s, a long run unchanged (29.6); 24 on 24
+    # collapses (10-24 Grays/s, the process runs out of hardware queues), so ranks that also run RCCL stay at 16.
+    if args.inflight <= 0:
+        args.inflight = 20 if int(os.environ.get("WORLD_SIZE", "1")) == 1 else 16
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(1, min(args.inflight, 24))))
     import torch
     import rays1bench_amd as r1

@@ -271,7 +271,7 @@ int r1_multi_info(r1_multi *m, int32_t *n_devices, int32_t *rccl_version, r1_lau
  * structure, README.md:163).  Builds it on the host exactly as r1_set_scene does.  Optional
  * outputs: `nodes_out` receives 16 floats per inner node {m0x m1x m0y m1y | m0z m1z e0x e1x |
  * e0y e1y e0z e1z | A K child0 child1} (child i: box centre m_i, half extent e_i, both inflated
- * per ray by A |o - info.centre|^2 + K; reference:
+ * per ray by A |o - info.centre|^2 + K, or A |m_0 + m_1 - 2 o|^2 + K if info.pad_local; reference:
  * bit 31 = leaf, then bits 28..30 = number of sphere PAIRS and bits 0..27 the first pair; else
  * inner node index), `ids_out[2 * pair + {0, 1}]` the scene index of each leaf sphere
  * (0xFFFFFFFF = the empty partner of an odd sphere); needs 2 * info.pairs entries.
@@ -279,7 +279,8 @@ int r1_multi_info(r1_multi *m, int32_t *n_devices, int32_t *rccl_version, r1_lau
 typedef struct r1_bvh_info
 {
     int32_t nodes, leaves, depth, stack_entries, spheres, pairs;
-    float centre[3]; /* C of the kernel's box inflation pad = A |o - C|^2 + K (r1_bvh.cpp) */
+    float centre[3];   /* C of the kernel's box inflation pad = A |o - C|^2 + K (r1_bvh.cpp) */
+    int32_t pad_local; /* 1: the tree uses pad = A |m0 + m1 - 2 o|^2 + K instead (scenes of small spheres) */
 } r1_bvh_info;
 int r1_bvh_describe(const r1_scene *scene, int32_t leaf_max, r1_bvh_info *info, float *nodes_out, size_t nodes_cap, uint32_t *ids_out,
                     size_t ids_cap);

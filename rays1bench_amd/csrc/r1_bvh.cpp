@@ -32,6 +32,17 @@
 // the errors budgeted above it adds u |o| (1 + u) in position units, and |o| <= |o - C| + |C| <=
 // (1 + R2) / 2 + |C|.  A and K are rounded up with 2^-18 relative headroom for the fp32 evaluation
 // of R2 (3 u) and of the fused multiply-add (u).
+//
+// Scenes of small spheres (R1Bvh::pad_local; the 100 004-sphere lattice: r = 0.034, spacing 0.08): w2 grows with 1 / r and
+// a pad measured from ONE point of the scene (~0.1 there) would bury the boxes.  Such trees measure the distance per node:
+//      pad = A * |s|^2 + K,   s = m0 + m1 - 2 o = 2 (m_n - o),  m_n the midpoint of the two child centres,
+// A = (1 + eps) w2 / 4 + u / 8, K = k + (1 + 1 / eps) w2 g^2 + u (1/2 + |m_n|) + ..., g = |m0 - m1| / 2 = |m_c - m_n|:
+// |m_c - o|^2 <= (|m_n - o| + g)^2 <= (1 + eps) |s|^2 / 4 + (1 + 1 / eps) g^2 for every eps > 0 (eps = g / the scene's
+// scale: tight for origins that far away), and |o| <= |s| / 2 + |m_n| <= (1 + |s|^2 / 4) / 2 + |m_n|.  s is computed in
+// fp32 (error per component <= delta = 4 u (|m0|_inf + |m1|_inf + 2 |o|_inf) <= 4 u (3 M + |s|), M = |m0|_inf + |m1|_inf);
+// |s|^2 <= (1 + 2^-10) |s'|^2 + (1 + 2^10) 3 delta^2 puts 2^-10 more on A and A 3075 * 288 u^2 M^2 on K (the |s|^2
+// part of delta^2 is 1e-10 relative).  9 VALU instructions per node visit instead of 1, still 7 fewer than round 1's form.
+// The choice is made per tree from the median radius and the median distance from C: local when 4 w2_med G^2 > r_med / 4.
 // Every constant is rounded up.  Extra visits are harmless: leaves apply the reference's rule.
 #include <hip/hip_runtime.h>
 
@@ -53,6 +64,7 @@ struct R1Bvh
     int max_depth = 0;          // inner nodes on the longest root-to-leaf path
     uint32_t n_leaves = 0;
     float centre[3] = {0, 0, 0}; // C of the pad formula (see above)
+    int pad_local = 0;           // 1: pad measured per node (scenes of small spheres), 0: from `centre`
 };
 
 namespace
@@ -104,6 +116,8 @@ struct Builder
     R1Bvh *out;
     int leaf_max;
     double centre[3]; // C of the pad formula, == out->centre
+    bool pad_local = false;
+    double d_typ = 1.0; // pad_local: the distance at which the per-node pad is tight (twice the median distance of the centres from C)
 
     static const uint32_t LEAF = 0x80000000u;
 
@@ -288,19 +302,40 @@ struct Builder
         encode(b0, m0, e0, w0, k0);
         encode(b1, m1, e1, w1, k1);
         float *p = &out->nodes[16 * (size_t)node];
-        // pad = A |o - C|^2 + K (see the header): >= w2 |m - o|^2 + k for both children
-        double g2 = 0;
-        for (const float *m : {m0, m1})
-        {
-            double q = 0;
-            for (int a = 0; a < 3; ++a)
-                q += ((double)m[a] - centre[a]) * ((double)m[a] - centre[a]);
-            g2 = std::max(g2, q);
-        }
+        // pad = A |o - C|^2 + K, or A |m0 + m1 - 2 o|^2 + K (see the header): >= w2 |m - o|^2 + k for both children
         const double u = ldexp(1.0, -24), w2 = std::max(w0, w1), k = std::max(k0, k1);
-        const double c1n = std::fabs(centre[0]) + std::fabs(centre[1]) + std::fabs(centre[2]);
         const double head = 1.0 + ldexp(1.0, -18);
-        const float A = round_up((2.0 * w2 + u) * head), K = round_up((k + 2.0 * w2 * g2 + u * (1.0 + c1n)) * head);
+        float A, K;
+        if (!pad_local)
+        {
+            double g2 = 0;
+            for (const float *m : {m0, m1})
+            {
+                double q = 0;
+                for (int a = 0; a < 3; ++a)
+                    q += ((double)m[a] - centre[a]) * ((double)m[a] - centre[a]);
+                g2 = std::max(g2, q);
+            }
+            const double c1n = std::fabs(centre[0]) + std::fabs(centre[1]) + std::fabs(centre[2]);
+            A = round_up((2.0 * w2 + u) * head), K = round_up((k + 2.0 * w2 * g2 + u * (1.0 + c1n)) * head);
+        }
+        else
+        {
+            double g2 = 0, mn2 = 0, M = 0, M0 = 0, M1 = 0;
+            for (int a = 0; a < 3; ++a)
+            {
+                const double h = 0.5 * ((double)m0[a] - (double)m1[a]), mn = 0.5 * ((double)m0[a] + (double)m1[a]);
+                g2 += h * h, mn2 += mn * mn;
+                M0 = std::max(M0, std::fabs((double)m0[a])), M1 = std::max(M1, std::fabs((double)m1[a]));
+            }
+            M = M0 + M1;
+            // (D + g)^2 <= (1 + eps) D^2 + (1 + 1 / eps) g^2 for every eps > 0: tight at D = g / eps.  eps = g / d_typ makes the
+            // pad exact for origins d_typ away (the scene's scale), instead of twice what is needed (eps = 1) everywhere
+            const double eps = std::min(1.0, std::max(1.0 / 64.0, std::sqrt(g2) / d_typ));
+            const double a_loc = (0.25 * (1.0 + eps) * w2 + u / 8.0) * (1.0 + ldexp(1.0, -10));
+            A = round_up(a_loc * head);
+            K = round_up((k + (1.0 + 1.0 / eps) * w2 * g2 + u * (0.5 + std::sqrt(mn2)) + a_loc * 3075.0 * 288.0 * u * u * M * M) * head);
+        }
         // {m0x m1x m0y m1y} {m0z m1z e0x e1x} {e0y e1y e0z e1z} {A K child0 child1}
         p[0] = m0[0], p[1] = m1[0], p[2] = m0[1], p[3] = m1[1];
         p[4] = m0[2], p[5] = m1[2], p[6] = e0[0], p[7] = e1[0];
@@ -361,6 +396,31 @@ void r1_build_bvh(uint32_t na, const float *cx, const float *cy, const float *cz
         }
         out.centre[k] = (float)med;
         B.centre[k] = (double)out.centre[k]; // exactly the fp32 value the kernel subtracts
+    }
+    // pad formula of this tree (see the header): per node for scenes of small spheres
+    {
+        std::vector<double> rr(na), dd(na);
+        for (uint32_t a = 0; a < na; ++a)
+        {
+            rr[a] = B.sphere[a].rmax;
+            const double dx = cx[a] - B.centre[0], dy = cy[a] - B.centre[1], dz = cz[a] - B.centre[2];
+            dd[a] = dx * dx + dy * dy + dz * dz;
+        }
+        bool local = false;
+        if (na)
+        {
+            std::nth_element(rr.begin(), rr.begin() + na / 2, rr.end());
+            std::nth_element(dd.begin(), dd.begin() + na / 2, dd.end());
+            const double r_med = std::max(rr[na / 2], 1e-30), G2 = 4.0 * dd[na / 2];
+            const double w2_med = 80.0 * ldexp(1.0, -24) / (2.0 * r_med) + ldexp(1.0, -19);
+            local = 4.0 * w2_med * G2 > 0.25 * r_med;
+        }
+        static const int pad_env = getenv("R1_BVH_PAD_LOCAL") ? atoi(getenv("R1_BVH_PAD_LOCAL")) : -1; // tuning experiments
+        if (pad_env >= 0)
+            local = pad_env != 0;
+        B.pad_local = local;
+        B.d_typ = na ? std::max(std::sqrt(4.0 * dd[na / 2]), 1e-30) : 1.0;
+        out.pad_local = local ? 1 : 0;
     }
     // the root is node 0
     out.nodes.resize(16);
@@ -476,6 +536,7 @@ extern "C" int r1_bvh_describe(const r1_scene *s, int32_t leaf_max, r1_bvh_info 
     info->spheres = (int32_t)na;
     for (int k = 0; k < 3; ++k)
         info->centre[k] = b.centre[k];
+    info->pad_local = b.pad_local;
     if (nodes_out)
     {
         if (nodes_cap < b.nodes.size())

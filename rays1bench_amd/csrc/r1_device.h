@@ -39,7 +39,7 @@
 #define R1_TREE_SKIP_MAX 128   // spheres, box tree otherwise
 #define R1_SUBQUEUES 16        // latency mode: sub-queues of the sample queue (R1TraceArgs::nq)
 #define R1_COUNTER_BYTES 4096  // per-context counter block: queue heads, ray count, drain counts, stats, sub-queues at +1024
-#define R1_COOP_LANES 4        // R1TraceArgs::coop_lanes
+#define R1_COOP_LANES 2        // R1TraceArgs::coop_lanes (one synchronous frame: 2 -> 1.144 ms, 4 -> 1.160, 8 -> 1.193, 16 -> 1.263)
 
 // Division of n < 2^31 by a launch constant: pow2 ? n >> shift : mulhi(n, mul) >> shift, with
 // mul = ceil(2^(32+shift) / d), shift = floor(log2 d) (exact for every n < 2^31; r1_capi.cpp).
@@ -75,6 +75,7 @@ struct R1DeviceScene
     const float4 *bvh_prims;
     const uint32_t *bvh_ids;
     float bvh_centre[3];
+    uint32_t bvh_pad_local; // 1: pad = A |m0 + m1 - 2 o|^2 + K (scenes of small spheres, r1_bvh.cpp)
 };
 
 struct R1DeviceCamera

@@ -742,7 +742,13 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
                     q0 = nodes[4 * (size_t)cur + 0], q1 = nodes[4 * (size_t)cur + 1], q2 = nodes[4 * (size_t)cur + 2],
                     q3 = nodes[4 * (size_t)cur + 3];
                 float tn0, tn1;
-                const float pad = __fmaf_rn(q3.x, r2, q3.y);
+                float dist2 = r2;
+                if (S.bvh_pad_local) // wave-uniform: scenes of small spheres measure the pad's distance per node, |m0 + m1 - 2 o|^2
+                {
+                    const float sx = __fmaf_rn(-2.0f, o.x, q0.x + q0.y), sy = __fmaf_rn(-2.0f, o.y, q0.z + q0.w), sz = __fmaf_rn(-2.0f, o.z, q1.x + q1.y);
+                    dist2 = __fmaf_rn(sz, sz, __fmaf_rn(sy, sy, sx * sx));
+                }
+                const float pad = __fmaf_rn(q3.x, dist2, q3.y);
                 const V3 pa = mk(pad * ainv.x, pad * ainv.y, pad * ainv.z);
                 const bool h0 = bvh_box(q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, pa, oi, inv, ainv, best, tn0);
                 const bool h1 = bvh_box(q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, pa, oi, inv, ainv, best, tn1);
@@ -801,7 +807,13 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
                 q0 = nodes[4 * (size_t)cur + 0], q1 = nodes[4 * (size_t)cur + 1], q2 = nodes[4 * (size_t)cur + 2],
                 q3 = nodes[4 * (size_t)cur + 3];
             float tn0, tn1;
-            const float pad = __fmaf_rn(q3.x, r2, q3.y);
+            float dist2 = r2;
+            if (S.bvh_pad_local) // wave-uniform: scenes of small spheres measure the pad's distance per node, |m0 + m1 - 2 o|^2
+            {
+                const float sx = __fmaf_rn(-2.0f, o.x, q0.x + q0.y), sy = __fmaf_rn(-2.0f, o.y, q0.z + q0.w), sz = __fmaf_rn(-2.0f, o.z, q1.x + q1.y);
+                dist2 = __fmaf_rn(sz, sz, __fmaf_rn(sy, sy, sx * sx));
+            }
+            const float pad = __fmaf_rn(q3.x, dist2, q3.y);
             const V3 pa = mk(pad * ainv.x, pad * ainv.y, pad * ainv.z);
             const bool h0 = bvh_box(q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, pa, oi, inv, ainv, best, tn0);
             const bool h1 = bvh_box(q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, pa, oi, inv, ainv, best, tn1);

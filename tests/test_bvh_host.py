@@ -87,6 +87,9 @@ def test_tree_structure(kind, gw, gh):
             assert (c[i] - r[i] >= m - e - 1e-12).all() and (c[i] + r[i] <= m + e + 1e-12).all()
         assert w2 > 0 and k > 0
     assert n_leaf == info["leaves"]
+    # the pad formula follows the sphere size: measured from one point of the scene for the reference's scenes, per node
+    # for the lattices of small spheres (r1_bvh.cpp)
+    assert info["pad_local"] == (1 if kind == "grid" and gw == 400 else 0), info
     if kind == "grid" and gw == 400:
         assert info["depth"] <= 24 and info["spheres"] == 100004
 
@@ -108,7 +111,7 @@ def ref_flagged(cx, cy, cz, rsq, o, d):
     return ok & ((t1 > F(0.001)) | (t2 > F(0.001)))
 
 
-def traverse(nodes, centre, o, d, jitter=None):
+def traverse(nodes, centre, o, d, jitter=None, pad_local=0):
     """The kernel's visit rule (r1_kernels.hip::bvh_box, fp32 step by step) without distance pruning: leaf slots the ray is shown."""
     o = o.astype(F)
 
@@ -129,7 +132,11 @@ def traverse(nodes, centre, o, d, jitter=None):
             n = stack.pop()
             row = nodes[n]
             refs = row.view(np.uint32)
-            pad = fma(row[12], r2, row[13])
+            dist2 = r2
+            if pad_local:
+                sv = fma(F(-2), o, (row[list(M[0])] + row[list(M[1])]).astype(F))
+                dist2 = fma(sv[2], sv[2], fma(sv[1], sv[1], F(sv[0] * sv[0])))
+            pad = fma(row[12], dist2, row[13])
             pa = (pad * ainv).astype(F)
             for c in (0, 1):
                 a = fma(row[list(M[c])], inv, -oi)
@@ -173,7 +180,7 @@ def test_traversal_rule_presents_every_sphere_the_reference_flags(kind):
         if q % 7 == 0:
             d = np.array([0, 0, -1], F) if q % 2 else np.array([1, 0, 0], F)  # axis-parallel: infinite reciprocals
         flagged = set(np.nonzero(ref_flagged(cx, cy, cz, rsq, o, d) & active)[0].tolist())
-        shown = set(ids[traverse(nodes, info["centre"], o, d, rng.integers(0, 2, 3) * 2 - 1)].tolist()) - {EMPTY}
+        shown = set(ids[traverse(nodes, info["centre"], o, d, rng.integers(0, 2, 3) * 2 - 1, info["pad_local"])].tolist()) - {EMPTY}
         assert flagged <= shown, (q, sorted(flagged - shown)[:5])
         shown_total += len(shown)
         flagged_total += len(flagged)
@@ -226,7 +233,7 @@ def test_random_scenes_tree_invariants_and_visit_rule(seed):
         d = (target - o).astype(np.float64)
         d = (d / np.linalg.norm(d)).astype(F)
         flagged = set(np.nonzero(ref_flagged(cx, cy, cz, rsq, o, d))[0].tolist())
-        shown = set(ids[traverse(nodes, info["centre"], o, d, rng.integers(0, 2, 3) * 2 - 1)].tolist()) - {EMPTY}
+        shown = set(ids[traverse(nodes, info["centre"], o, d, rng.integers(0, 2, 3) * 2 - 1, info["pad_local"])].tolist()) - {EMPTY}
         assert flagged <= shown, (seed, q, sorted(flagged - shown)[:5])
 
 
@@ -300,7 +307,7 @@ def test_visit_rule_on_adversarial_families(family):
         d = target - o.astype(np.float64)
         d = (d / np.linalg.norm(d)).astype(F)
         flagged = set(np.nonzero(ref_flagged(cx, cy, cz, rsq, o, d))[0].tolist())
-        shown = set(ids[traverse(nodes, info["centre"], o, d, rng.integers(0, 2, 3) * 2 - 1)].tolist()) - {EMPTY}
+        shown = set(ids[traverse(nodes, info["centre"], o, d, rng.integers(0, 2, 3) * 2 - 1, info["pad_local"])].tolist()) - {EMPTY}
         assert flagged <= shown, (family, q, sorted(flagged - shown)[:5])
         hits += len(flagged)
     assert hits > 0  # the family does produce reference candidates (for degenerate radii: rounding-noise hits)
