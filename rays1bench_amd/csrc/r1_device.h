@@ -38,7 +38,8 @@
 #define R1_TREE_SKIP_MIN 9     // DEFAULT kernel: exhaustive sweep for scenes of [R1_TREE_SKIP_MIN, R1_TREE_SKIP_MAX) hittable
 #define R1_TREE_SKIP_MAX 128   // spheres, box tree otherwise
 #define R1_SUBQUEUES 16        // latency mode: sub-queues of the sample queue (R1TraceArgs::nq)
-#define R1_COUNTER_BYTES 4096  // per-context counter block: queue heads, ray count, drain counts, stats, sub-queues at +1024
+#define R1_COUNTER_BYTES 4096  // per-context counter block: queue heads, ray count (+32), drain counts, stats (+128), sub-queues at +1024;
+                               // the allocation carries 64 more bytes: the published ray count of the synchronous entry points
 #define R1_COOP_LANES 2        // R1TraceArgs::coop_lanes (one synchronous frame: 2 -> 1.144 ms, 4 -> 1.160, 8 -> 1.193, 16 -> 1.263)
 
 // Division of n < 2^31 by a launch constant: pow2 ? n >> shift : mulhi(n, mul) >> shift, with
@@ -147,6 +148,11 @@ struct R1ResolveArgs
     float inv_spp;               // (float)(1.0f / spp)
     uint8_t *out;                // row-major image or dense tile block
     int32_t block_layout;        // 0: row-major width*height*3, 1: dense tile block
+    // end of the frame (block (0,0), after the trace kernel): publish the ray count the trace kernel accumulated in the
+    // context's counter block, then zero the block for the next frame — two memset launches per frame less
+    const unsigned long long *rays_src; // null: the trace kernel counted into the caller's word itself
+    unsigned long long *rays_dst;
+    uint32_t *reset;             // R1_COUNTER_BYTES to zero, or null
 };
 
 #endif

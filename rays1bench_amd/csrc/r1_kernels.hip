@@ -1628,6 +1628,15 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_wf_shade(const R1WaveArgs W)
 // ============================================================================================
 __global__ void __launch_bounds__(256) r1_resolve_kernel(const R1ResolveArgs A)
 {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && A.rays_src)
+    {
+        static_assert(R1_COUNTER_BYTES == 256 * 16, "one 16-byte store per thread zeroes the counter block");
+        if (threadIdx.x == 0)
+            *A.rays_dst = *A.rays_src;
+        __syncthreads();
+        if (A.reset)
+            ((uint4 *)A.reset)[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+    }
     const uint32_t tiles_stride = gridDim.y;
     for (uint32_t lt = blockIdx.y; lt < A.n_local_tiles; lt += tiles_stride)
     {
