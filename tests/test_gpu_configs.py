@@ -418,3 +418,59 @@ def test_pixel_mode_writes_the_same_pixels_and_counts(case):
         assert rays2 == ref_rays and again.tobytes() == ref.tobytes() and int(rays_of(samples).sum()) == ref_rays
     finally:
         rend.close()
+
+
+def test_frame_sequences_on_one_context_keep_the_counter_block_consistent():
+    """The resolve launch of a frame publishes its ray count and zeroes the context's counter block for the NEXT frame
+    (r1_capi.cpp: fused_clear); diagnostic frames, PIXEL-mode frames and empty shards clear with memsets instead.  Every
+    order of these on ONE context must give the same counts and pixels: a frame that inherits a dirty block would
+    start with an advanced sample queue (too few rays) or a non-zero count (too many)."""
+    torch = pytest.importorskip("torch")
+    from rays1bench_amd import sharding
+    w, h, spp = 200, 120, 6
+    rend = r1.Renderer(0)
+    try:
+        rend.set_scene(r1.create_large_scene(w, h))
+        p = r1.make_params(w, h, spp, 5)
+        ref, ref_rays, _ = rend.render(p)
+        nbytes = binding.shard_block_bytes(p)
+        rec = torch.zeros(nbytes + sharding.RECORD_TRAILER, dtype=torch.uint8, device="cuda")
+        out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def device_frame(params=p):
+            rec.zero_()
+            rend.render_shard_device(params, rec.data_ptr(), rec.data_ptr() + nbytes, stream)
+            rend.assemble_device_strided(p, rec.data_ptr(), rec.numel(), out.data_ptr(), stream)
+            torch.cuda.synchronize()
+            return out.cpu().numpy().tobytes(), sharding.total_rays(rec, 1)
+
+        def host_frame(variant):
+            img, rays, _ = rend.render(r1.make_params(w, h, spp, 5, variant=variant))
+            return img.tobytes(), rays
+
+        want = (ref.tobytes(), ref_rays)
+        for step in ("device", "device", "stats", "device", "host", "sweep_stats", "host", "pixel", "device", "pixel_off", "device", "host",
+                     "wavefront", "device", "reference", "host"):
+            if step == "device":
+                got = device_frame()
+            elif step == "host":
+                got = host_frame(binding.VARIANT_DEFAULT)
+            elif step == "stats":
+                got = host_frame(binding.VARIANT_BVH_STATS)
+            elif step == "sweep_stats":
+                got = host_frame(binding.VARIANT_STATS)
+            elif step == "wavefront":
+                got = host_frame(binding.VARIANT_WAVEFRONT)
+            elif step == "reference":
+                got = host_frame(binding.VARIANT_REFERENCE)
+            elif step == "pixel":
+                rend.set_pixel_mode(True)
+                got = device_frame()
+            else:
+                rend.set_pixel_mode(False)
+                got = device_frame()
+            assert got[1] == want[1], (step, got[1], want[1])
+            assert got[0] == want[0], step
+    finally:
+        rend.close()

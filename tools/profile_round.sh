@@ -5,7 +5,7 @@
 #   2. HBM traffic of the trace kernel: --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (default and --pixel-mode)
 #   3. SQ counters of the throughput-mode trace kernel (instruction counts, busy / wait cycles)
 #   4. the bench line itself (with cpu_baseline), the other BASELINE configs on one GPU, emulated per-rank loads
-#   5. diagnostics: traversal counters, per-wave timeline of a synchronous frame, issue-cost and atomic micro-benchmarks
+#   5. diagnostics: traversal counters, per-wave timeline of a synchronous frame, tree against sweep by sphere count, issue-cost and atomic micro-benchmarks
 TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
@@ -33,6 +33,7 @@ timeout -k 10 120 python tools/bvh_stats.py large 1200 800 10 > $OUT/traversal_s
 timeout -k 10 120 python tools/kernel_stats.py large 1200 800 10 > $OUT/phase_stats_sweep_kernel.txt 2>&1
 timeout -k 10 120 python tools/wave_timeline.py > $OUT/wave_timeline_sync_frame.txt 2>&1
 timeout -k 10 120 python tools/host_costs.py > $OUT/host_costs.txt 2>&1
+timeout -k 10 200 python tools/tree_crossover.py > $OUT/tree_vs_sweep_crossover.txt 2>&1
 timeout -k 10 120 rays1bench_amd/lib/ubench_isa > $OUT/isa_issue_costs.txt 2>&1
 timeout -k 10 120 rays1bench_amd/lib/ubench_atomic > $OUT/atomic_queue_rates.txt 2>&1
 python3 - <<PY

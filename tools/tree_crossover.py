@@ -22,6 +22,27 @@ cam = src.camera.contents
 active = np.nonzero(arr["inv_radius"] != 0)[0]
 big, lattice = active[-4:], active[:-4]
 rend = r1.Renderer(0)
+
+
+def both(label):
+    res = {}
+    for name, v in (("sweep", binding.VARIANT_PREFILTER), ("tree", binding.VARIANT_BVH)):
+        p = r1.make_params(w, h, spp, 10001, variant=v)
+        ms = []
+        for i in range(14):
+            out = np.zeros((h, w, 3), np.uint8)
+            rays, _ = rend.render_into(p, out)
+            if i >= 2:
+                ms.append(rend.last_timing()[1])
+        res[name] = (statistics.median(ms), rays, out)
+    same = res["sweep"][1] == res["tree"][1] and (res["sweep"][2] == res["tree"][2]).all()
+    print(f"{label}: sweep {res['sweep'][0]:.3f} ms  tree {res['tree'][0]:.3f} ms  -> {'tree' if res['tree'][0] < res['sweep'][0] else 'sweep'}  "
+          f"(rays {res['tree'][1]}, identical {same})")
+
+
+for name, make in (("small scene", r1.create_small_scene), ("medium scene", r1.create_medium_scene)):
+    rend.set_scene(make(w, h))
+    both(name)
 for n in (1, 4, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 480):
     keep = np.concatenate([lattice[:: max(1, len(lattice) // n)][:n], big])
     sub = {k: np.ascontiguousarray(v[keep]) for k, v in arr.items()}
@@ -36,16 +57,4 @@ for n in (1, 4, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 480):
             setattr(cs, k, v.ctypes.data_as(C.POINTER(C.c_float)))
     cs.mat_type = sub["mat_type"].ctypes.data_as(C.POINTER(C.c_uint8))
     rend.set_scene_raw(cs, cam)
-    res = {}
-    for name, v in (("sweep", binding.VARIANT_PREFILTER), ("tree", binding.VARIANT_BVH)):
-        p = r1.make_params(w, h, spp, 10001, variant=v)
-        ms = []
-        for i in range(14):
-            out = np.zeros((h, w, 3), np.uint8)
-            rays, _ = rend.render_into(p, out)
-            if i >= 2:
-                ms.append(rend.last_timing()[1])
-        res[name] = (statistics.median(ms), rays, out)
-    same = res["sweep"][1] == res["tree"][1] and (res["sweep"][2] == res["tree"][2]).all()
-    print(f"{len(keep):4d} spheres: sweep {res['sweep'][0]:.3f} ms  tree {res['tree'][0]:.3f} ms  -> {'tree' if res['tree'][0] < res['sweep'][0] else 'sweep'}  "
-          f"(rays {res['tree'][1]}, identical {same})")
+    both(f"{len(keep):4d} spheres")
