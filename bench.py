@@ -211,7 +211,7 @@ def main():
     # 20 in flight on 20 queues: the driver's short run (20 steps) 26.3 -> 27.1 Grays/s, a long run unchanged (29.6); 24 on 24
     # collapses (10-24 Grays/s, the process runs out of hardware queues), so ranks that also run RCCL stay at 16.
     if args.inflight <= 0:
-        args.inflight = 20 if int(os.environ.get("WORLD_SIZE", "1")) == 1 else 16
+        args.inflight = 20 if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.emulate_shards <= 1 else 16
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(1, min(args.inflight, 24))))
     import torch
     import rays1bench_amd as r1
