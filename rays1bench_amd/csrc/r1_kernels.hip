@@ -1301,7 +1301,8 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
     trav_start(tv);
     tv.cur = R1_BVH_DONE;
     unsigned long long lane_rays = 0;
-    // Tree kernels, frames in flight (MODE 0): every lane keeps ONE prepared sample (its primary ray and stream states,
+    // Frames in flight (MODE 0; tree kernels and the small-scene exhaustive sweep, 18.25 -> 19.0 Grays/s at 96 VGPRs, its
+    // limit for five waves per SIMD): every lane keeps ONE prepared sample (its primary ray and stream states,
     // 11 registers) next to the path it is tracing.  A lane whose path ends takes its own spare, and spares are generated
     // for all lanes that lack one at once — when a lane has died without one, or R1_SPARE_MIN lanes lack one — instead of
     // for the ~36 % of the lanes that died in this iteration: the ~200 instructions of hashing, lens disk and camera ray
@@ -1314,7 +1315,7 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
 #ifndef R1_SPARE_MIN
 #define R1_SPARE_MIN 40u
 #endif
-    constexpr bool SPARE = R1_SPARE && VARIANT == 4 && MODE == 0;
+    constexpr bool SPARE = R1_SPARE && (VARIANT == 4 || (VARIANT == 2 && !BIG)) && MODE == 0;
     Path spare = p;
     bool has_spare = false;
 
