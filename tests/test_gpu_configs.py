@@ -474,3 +474,43 @@ def test_frame_sequences_on_one_context_keep_the_counter_block_consistent():
             assert got[0] == want[0], step
     finally:
         rend.close()
+
+
+@pytest.mark.parametrize("case", ["large_tree", "large_sweep", "medium", "small", "grid_2600_tree", "large_250spp"])
+def test_throughput_entry_point_equals_the_synchronous_one(case):
+    """r1_render_shard_device runs the frames-in-flight kernels (one queue, majority walk, a prepared spare sample per
+    lane), r1_render the synchronous-frame kernels (sub-queues, cooperative tail, no spares): same pixels, same count —
+    which sample a lane traces when is not supposed to matter."""
+    torch = pytest.importorskip("torch")
+    from rays1bench_amd import sharding
+    variant = binding.VARIANT_DEFAULT
+    if case == "large_tree":
+        sc, w, h, spp, variant = r1.create_large_scene(1200, 800), 1200, 800, 10, binding.VARIANT_BVH
+    elif case == "large_sweep":
+        sc, w, h, spp, variant = r1.create_large_scene(1200, 800), 1200, 800, 10, binding.VARIANT_PREFILTER
+    elif case == "medium":
+        sc, w, h, spp = r1.create_medium_scene(640, 400), 640, 400, 7
+    elif case == "small":
+        sc, w, h, spp = r1.create_small_scene(333, 211), 333, 211, 9
+    elif case == "grid_2600_tree":
+        sc, w, h, spp = r1.create_grid_scene(320, 200, 64, 40), 320, 200, 5
+    else:
+        sc, w, h, spp = r1.create_large_scene(160, 96), 160, 96, 250
+    rend = r1.Renderer(0)
+    try:
+        rend.set_scene(sc)
+        p = r1.make_params(w, h, spp, 4242, variant=variant)
+        ref, ref_rays, _ = rend.render(p)
+        nbytes = binding.shard_block_bytes(p)
+        rec = torch.zeros(nbytes + sharding.RECORD_TRAILER, dtype=torch.uint8, device="cuda")
+        out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        for _ in range(2):  # twice: the second frame inherits the counter block the first one's resolve launch cleared
+            rec.zero_()
+            rend.render_shard_device(p, rec.data_ptr(), rec.data_ptr() + nbytes, stream)
+            rend.assemble_device_strided(p, rec.data_ptr(), rec.numel(), out.data_ptr(), stream)
+            torch.cuda.synchronize()
+            assert sharding.total_rays(rec, 1) == ref_rays
+            assert out.cpu().numpy().tobytes() == ref.tobytes()
+    finally:
+        rend.close()
