@@ -681,7 +681,7 @@ __device__ __forceinline__ void trav_start(Trav &t)
 }
 
 #ifndef R1_CARRY_DIV
-#define R1_CARRY_DIV 4u // a walk phase ends when at most 1 / R1_CARRY_DIV of the live lanes are still walking
+#define R1_CARRY_DIV 6u // a walk phase ends when at most 1 / R1_CARRY_DIV of the live lanes are still walking (2 / 3 / 4 / 6 / 8: 30.3 / 31.6 / 31.9 / 32.1 / 32.0 Grays/s)
 #endif
 // Advances every lane whose walk is not complete.  CARRY = false: until all walks are complete (the
 // classic while-while loop).  CARRY = true: returns as soon as at most a quarter of the `n_alive` live
@@ -1309,6 +1309,13 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
     // run every second iteration at ~60 % of the lanes.  29.4 -> 30.5 Grays/s (thresholds 20 / 32 / 44 / never by count:
     // 30.2 / 30.5 / 30.6 / 30.4).  Not for a synchronous frame: what the lanes hold when the queue runs dry is the
     // frame's tail (1.17 -> 1.23 ms with spares).
+// One step per trip by majority vote (bvh_advance<..., MAJORITY = true>) was +1.5 % for frames in flight while a node visit
+// was four global loads; with the node table in LDS the vote's ~20 instructions per trip cost more than the fuller trips
+// bring: while-while + carry-over 32.0 against 30.5 Grays/s (and 1.16 against 1.27 ms for a synchronous frame).  The
+// voting walk stays in the source as an option of the build.
+#ifndef R1_TP_MAJORITY
+#define R1_TP_MAJORITY 0
+#endif
 #ifndef R1_SPARE
 #define R1_SPARE 1
 #endif
@@ -1477,7 +1484,7 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
         {
             // frames in flight (and the diagnostic build, whose counts go with that line): one step per trip by
             // majority; a synchronous frame: while-while.  Both carry unfinished walks over.
-            bvh_advance<STATS, true, (STATS || !LAT), LN>(A.scene, p.o, p.d, tv, s_trav, tid, (uint32_t)__popcll(live_now), wstat, lnodes);
+            bvh_advance<STATS, true, (R1_TP_MAJORITY && (STATS || !LAT)), LN>(A.scene, p.o, p.d, tv, s_trav, tid, (uint32_t)__popcll(live_now), wstat, lnodes);
             ready = alive && tv.cur == R1_BVH_DONE;
             if (tv.best_id != 0xFFFFFFFFu)
                 t_hit = tv.best, hit = (int)tv.best_id;
