@@ -529,12 +529,11 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
     c->n_bvh_nodes = (uint32_t)(bvh.nodes.size() / 16);
     c->n_bvh_leaves = bvh.n_leaves;
     c->bvh_depth = bvh.max_depth;
-    memset(c->occupancy, 0, sizeof(c->occupancy)); // the tree kernels' dynamic LDS follows the scene
     for (int k = 0; k < 3; ++k)
         c->bvh_centre[k] = bvh.centre[k];
     c->bvh_pad_local = bvh.pad_local;
     for (int &o : c->occupancy)
-        o = 0; // the tree kernels' LDS footprint follows the tree depth
+        o = 0; // the tree kernels' LDS footprint follows the tree (depth of the traversal stack, size of the node table)
     c->n_groups = ng;
     c->n_multi = n_multi;
 
