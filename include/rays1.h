@@ -22,7 +22,8 @@
  * once per process as tuning aids for the measurements under tools/ and profiles/ (launch
  * geometry: R1_SAMPLES_PER_LANE, R1_MIN_BLOCKS, R1_BLOCKS_PER_CU, R1_CHUNK, R1_CHUNK_MIN, R1_NQ,
  * R1_COOP_LANES, R1_TP_MODE; builders of the sweep groups and of the box tree: R1_GROUP_MAX,
- * R1_GROUP_RATIO, R1_BVH_LEAF, R1_BVH_PEEL, R1_BVH_PEEL_RATIO, R1_BVH_PAD_LOCAL).  They only
+ * R1_GROUP_RATIO, R1_BVH_LEAF, R1_BVH_PEEL, R1_BVH_PEEL_RATIO, R1_BVH_PAD_LOCAL, R1_BVH_TOP,
+ * R1_BIG_TOP).  They only
  * choose among launch shapes and conservative index layouts that produce the same pixels and
  * ray counts; unset (the shipped defaults) is what every number in DESIGN.md refers to.
  */

@@ -464,6 +464,77 @@ void r1_build_bvh(uint32_t na, const float *cx, const float *cy, const float *cz
         const uint32_t root = B.build(0, na, 0, all);
         (void)root; // == 0
     }
+    // Node order: the top of the tree breadth first (the first R1_BVH_TOP_NODES nodes = the levels every walk starts
+    // with, which the big-scene kernels keep in LDS), the rest depth first below them (a parent next to its first child,
+    // as build() allocates them).  Child references are rewritten; node 0 stays the root.
+    {
+        const uint32_t nn = (uint32_t)(out.nodes.size() / 16);
+        static const int top_env = getenv("R1_BVH_TOP") ? atoi(getenv("R1_BVH_TOP")) : R1_BVH_TOP_NODES; // tuning experiments
+        const uint32_t top = (uint32_t)std::max(0, top_env);
+        if (nn > 1 && top > 1)
+        {
+            auto child = [&](uint32_t n, int c) {
+                uint32_t r;
+                memcpy(&r, &out.nodes[16 * (size_t)n + 14 + c], 4);
+                return r;
+            };
+            std::vector<uint32_t> order_new; // old index of the node at each new position
+            order_new.reserve(nn);
+            std::vector<uint32_t> frontier(1, 0u);
+            size_t head = 0;
+            while (head < frontier.size() && frontier.size() < top) // breadth first until `top` nodes are known
+            {
+                const uint32_t n = frontier[head++];
+                for (int c = 0; c < 2; ++c)
+                    if (!(child(n, c) & Builder::LEAF))
+                        frontier.push_back(child(n, c));
+            }
+            // frontier[0 .. head) are expanded, frontier[head ..) are the roots of the remaining subtrees
+            std::vector<char> placed(nn, 0);
+            for (uint32_t n : frontier)
+                order_new.push_back(n), placed[n] = 1;
+            for (size_t f = head; f < frontier.size(); ++f) // depth first below every unexpanded top node
+            {
+                std::vector<uint32_t> stack;
+                for (int c = 1; c >= 0; --c)
+                    if (!(child(frontier[f], c) & Builder::LEAF))
+                        stack.push_back(child(frontier[f], c));
+                while (!stack.empty())
+                {
+                    const uint32_t n = stack.back();
+                    stack.pop_back();
+                    if (placed[n])
+                        continue;
+                    order_new.push_back(n), placed[n] = 1;
+                    for (int c = 1; c >= 0; --c)
+                        if (!(child(n, c) & Builder::LEAF))
+                            stack.push_back(child(n, c));
+                }
+            }
+            if (order_new.size() == nn)
+            {
+                std::vector<uint32_t> new_of(nn);
+                for (uint32_t i = 0; i < nn; ++i)
+                    new_of[order_new[i]] = i;
+                std::vector<float> moved(out.nodes.size());
+                for (uint32_t i = 0; i < nn; ++i)
+                {
+                    memcpy(&moved[16 * (size_t)i], &out.nodes[16 * (size_t)order_new[i]], 64);
+                    for (int c = 0; c < 2; ++c)
+                    {
+                        uint32_t r;
+                        memcpy(&r, &moved[16 * (size_t)i + 14 + c], 4);
+                        if (!(r & Builder::LEAF))
+                        {
+                            r = new_of[r];
+                            memcpy(&moved[16 * (size_t)i + 14 + c], &r, 4);
+                        }
+                    }
+                }
+                out.nodes.swap(moved);
+            }
+        }
+    }
     // keep the tables non-empty for the uploader
     if (out.prims.empty())
         out.prims.assign(8, 0.0f), out.ids.assign(2, 0xFFFFFFFFu);

@@ -700,7 +700,9 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     // kernels keep the first 3 * R1_STACK_LDS_WORDS stack entries in LDS and use the workspace beyond.
     const int big = big_scene_;
     a.bvh_depth = c->bvh_depth > 0 ? c->bvh_depth : 1;
-    a.bvh_lds_f4 = ((variant == 4 || variant == 5) && !big) ? 4u * c->n_bvh_nodes : 0u; // the workgroups' LDS copy of the node table
+    // the workgroups' LDS copy of the node table: all of it for small scenes, the breadth-first top for big ones
+    static const int big_top_env = getenv("R1_BIG_TOP") ? atoi(getenv("R1_BIG_TOP")) : R1_BVH_TOP_NODES; // tuning experiments
+    a.bvh_lds_f4 = !(variant == 4 || variant == 5) ? 0u : (!big ? 4u * c->n_bvh_nodes : 4u * std::min<uint32_t>(c->n_bvh_nodes, (uint32_t)std::max(0, big_top_env)));
     const int occ_slot = variant + 8 * big + 16 * mode;
     if (c->occupancy[occ_slot] == 0)
         R1_HIP(r1_trace_occupancy(variant, big, mode,

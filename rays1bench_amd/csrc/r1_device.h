@@ -34,6 +34,7 @@
 #define R1_MAX_ACTIVE (1u << 21) // big-scene kernels: 26-bit pair indices, limit kept at 2 M spheres
 #define R1_STACK_ENTRIES 51
 #define R1_BVH_STACK 32        // R1_VARIANT_BVH: per-lane traversal stack entries in LDS = most inner nodes on a path
+#define R1_BVH_TOP_NODES 63    // box tree: the first nodes in breadth-first order (6 levels); the big-scene kernels keep them in LDS (4 KB: 0 / 63 / 127 / 255 nodes -> 12.9 / 13.3 / 13.0 / 12.6 Grays/s on 100 004 spheres, the larger copies cost workgroups per CU)
 #define R1_BVH_LEAF 4          // spheres per leaf (<= 14; stored as pairs)
 #define R1_TREE_SKIP_MIN 9     // DEFAULT kernel: exhaustive sweep for scenes of [R1_TREE_SKIP_MIN, R1_TREE_SKIP_MAX) hittable
 #define R1_TREE_SKIP_MAX 128   // spheres, box tree otherwise

@@ -697,7 +697,7 @@ __device__ __forceinline__ void trav_start(Trav &t)
 // LN: the node table is read from `lnodes`, the workgroup's copy in LDS (the trace kernel on small scenes), instead of S.bvh_nodes.
 template <bool STATS, bool CARRY, bool MAJORITY, bool LN>
 __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, const V3 d, Trav &tv, uint32_t *trav, const int tid,
-                                            const uint32_t n_alive, unsigned long long *wstat, const float4 *lnodes /* LDS */)
+                                            const uint32_t n_alive, unsigned long long *wstat, const float4 *lnodes /* LDS */, const uint32_t top = 0u /* !LN: nodes [0, top) are in lnodes */)
 {
     const float4 *__restrict__ nodes = S.bvh_nodes;
     const float4 *__restrict__ prims = S.bvh_prims;
@@ -736,8 +736,12 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
                         wstat[2] += 1;
                 }
                 float4 q0, q1, q2, q3;
-                if (LN)
+                if (LN || cur < top) // (big scenes: the top of the tree, breadth first, is in LDS too; per lane)
+                {
                     q0 = lnodes[4 * cur + 0], q1 = lnodes[4 * cur + 1], q2 = lnodes[4 * cur + 2], q3 = lnodes[4 * cur + 3];
+                    if (!LN) // keeps the two loads apart: merged, they become one load through a generic pointer (flat_load_dword x 16)
+                        asm volatile("" : "+v"(q0.x), "+v"(q1.x), "+v"(q2.x), "+v"(q3.x));
+                }
                 else
                     q0 = nodes[4 * (size_t)cur + 0], q1 = nodes[4 * (size_t)cur + 1], q2 = nodes[4 * (size_t)cur + 2],
                     q3 = nodes[4 * (size_t)cur + 3];
@@ -801,8 +805,12 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
             }
             // {m0x m1x m0y m1y} {m0z m1z e0x e1x} {e0y e1y e0z e1z} {A K child0 child1}
             float4 q0, q1, q2, q3;
-            if (LN)
+            if (LN || cur < top)
+            {
                 q0 = lnodes[4 * cur + 0], q1 = lnodes[4 * cur + 1], q2 = lnodes[4 * cur + 2], q3 = lnodes[4 * cur + 3];
+                if (!LN)
+                    asm volatile("" : "+v"(q0.x), "+v"(q1.x), "+v"(q2.x), "+v"(q3.x));
+            }
             else
                 q0 = nodes[4 * (size_t)cur + 0], q1 = nodes[4 * (size_t)cur + 1], q2 = nodes[4 * (size_t)cur + 2],
                 q3 = nodes[4 * (size_t)cur + 3];
@@ -1281,8 +1289,10 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
     // answers sooner than the vector L1, and the table no longer competes with the sphere tables for its 32 KB:
     // 26.9 -> 29.3 Grays/s, one synchronous frame 1.34 -> 1.17 ms (large scene, 128 nodes = 8 KB).
     constexpr bool LN = VARIANT == 4 && !BIG;
-    const float4 *lnodes = (const float4 *)(s_trav + (LN ? (size_t)A.bvh_depth * R1_BLOCK : 0));
-    if (LN)
+    const float4 *lnodes = (const float4 *)(s_trav + (VARIANT == 4 ? (size_t)A.bvh_depth * R1_BLOCK : 0));
+    // (big scenes: A.bvh_lds_f4 covers the first nodes of the breadth-first top of the tree only)
+    const uint32_t top = LN ? 0u : A.bvh_lds_f4 >> 2;
+    if (VARIANT == 4 && A.bvh_lds_f4)
     {
         float4 *dst = (float4 *)(s_trav + (size_t)A.bvh_depth * R1_BLOCK);
         for (uint32_t i = (uint32_t)tid; i < A.bvh_lds_f4; i += R1_BLOCK)
@@ -1484,7 +1494,7 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
         {
             // small scenes (node table in LDS): while-while; big scenes in flight (and their diagnostic build, whose counts go
             // with that line): one step per trip by majority.  Both carry unfinished walks over.
-            bvh_advance<STATS, true, ((R1_TP_MAJORITY || !LN) && (STATS || !LAT)), LN>(A.scene, p.o, p.d, tv, s_trav, tid, (uint32_t)__popcll(live_now), wstat, lnodes);
+            bvh_advance<STATS, true, ((R1_TP_MAJORITY || !LN) && (STATS || !LAT)), LN>(A.scene, p.o, p.d, tv, s_trav, tid, (uint32_t)__popcll(live_now), wstat, lnodes, top);
             ready = alive && tv.cur == R1_BVH_DONE;
             if (tv.best_id != 0xFFFFFFFFu)
                 t_hit = tv.best, hit = (int)tv.best_id;
