@@ -12,8 +12,9 @@
 #define R1_PAIR_CAP_SMALL 512 // same, small scenes (bit path): 4 KB less LDS per workgroup = a fifth workgroup per CU
 #define R1_STACK_WORDS 17   // ceil(51 / 3) packed 10-bit hit indices per lane (max_bounces <= 51)
 #ifndef R1_STACK_LDS_WORDS
-#define R1_STACK_LDS_WORDS 8  // tree kernel, small scenes: words of the packed stack kept in LDS (24 entries); deeper entries (rare) go to
-#endif                        // the global workspace.  8 KB instead of 17: room for the node table at 6 workgroups per CU (4: -3 %, 12: -4 %)
+#define R1_STACK_LDS_WORDS 10 // tree kernel, small scenes: words of the packed stack kept in LDS (30 entries); deeper entries (rare) go to
+#endif                        // the global workspace.  10 KB instead of 17: room for the 128-node table (8 KB) and the traversal stack (8 KB)
+                              // at 6 workgroups per CU (27.3 KB each); 4 / 6 / 8 / 10 / 12 words: 28.4 / 29.1 / 29.3 (32.3) / (32.5) / 28.2 Grays/s
 #define R1_NODES_LDS_MAX 256  // tree kernel: scenes whose tree has at most this many nodes (16 KB) run the small-scene kernels, which keep
                               // the node table in LDS; bigger trees run the big-scene kernels (node table through the vector L1)
 #define R1_CHUNK 256        // most samples a wave takes from the global queue per atomic (small frames) ...

@@ -1237,7 +1237,7 @@ __device__ __forceinline__ bool shade_level(const R1TraceArgs &A, Path &p, const
 // STATS = diagnostic build (variant R1_VARIANT_STATS): same results, plus per-phase cycle and
 // utilisation counters in A.stats; never used by the product path.
 // Waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument): the
-// product kernels are sized by their LDS (tree: 6 workgroups per CU with a 128-node table — 8 KB attenuation stack + 8 KB
+// product kernels are sized by their LDS (tree: 6 workgroups per CU with a 128-node table — 10 KB attenuation stack + 8 KB
 // traversal stack + 8 KB nodes; exhaustive sweep: 5), so their VGPR count has to stay under 512 / 6 -> 80 and 512 / 5 -> 96.
 // The big-scene tree kernel waits for node fetches from L2, not for the VALU: it is built for 8 waves per SIMD (<= 64 VGPRs,
 // which it meets without the spare sample, and <= 96 SGPRs — at its natural 106 the 800 SGPRs of a SIMD hold seven waves):

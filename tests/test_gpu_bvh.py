@@ -180,7 +180,7 @@ def test_bvh_is_exact_on_adversarial_scenes(renderer, case):
 
 def test_bvh_deep_paths_between_two_huge_spheres(renderer):
     """A gap of two units between a floor and a ceiling sphere of radius 1000, bright Lambertian: paths bounce dozens of
-    times before they escape sideways to the sky, so the attenuation stack runs past the 24 entries the tree kernel
+    times before they escape sideways to the sky, so the attenuation stack runs past the 30 entries the tree kernel
     keeps in LDS (R1_STACK_LDS_WORDS; deeper entries live in the global workspace) and is unwound from there with a
     non-zero sky colour.  Bit-identical to the reference-form kernel (whole stack in LDS) and to the oracle."""
     rng = np.random.default_rng(77)
@@ -204,7 +204,7 @@ def test_bvh_deep_paths_between_two_huge_spheres(renderer):
     oimg, orays, osamples = r1o.render_frame(sa, oparams(r1.make_params(w, h, spp, 31)), want_samples=True)
     assert got[1] == orays and got[2].tobytes() == osamples.tobytes()
     n_rays = got[2][:, 3].copy().view(np.uint32)
-    deep_and_lit = (n_rays > 30) & (n_rays < 51) & (got[2][:, :3].sum(1) > 0)
+    deep_and_lit = (n_rays > 33) & (n_rays < 51) & (got[2][:, :3].sum(1) > 0)  # more than 30 stacked attenuations
     assert deep_and_lit.sum() > 20, int(deep_and_lit.sum())  # the deep entries are really unwound with colour
 
 
