@@ -1325,7 +1325,9 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
 // One step per trip by majority vote (bvh_advance<..., MAJORITY = true>) was +1.5 % for frames in flight while a node visit
 // was four global loads; with the node table in LDS the vote's ~20 instructions per trip cost more than the fuller trips
 // bring: while-while + carry-over 32.0 against 30.5 Grays/s (and 1.16 against 1.27 ms for a synchronous frame).  The
-// big-scene kernels, whose node table stays behind the vector L1, keep the vote (100 004 spheres: 13.1 against 12.5).
+// big-scene kernels, whose node table stays behind the vector L1, still preferred the vote at seven waves per SIMD (100 004
+// spheres: 13.1 against 12.5) and no longer do at eight (14.6 against 14.85): every product kernel walks while-while now,
+// the voting walk stays in the source as an option of the build.
 #ifndef R1_TP_MAJORITY
 #define R1_TP_MAJORITY 0
 #endif
@@ -1495,9 +1497,8 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
         }
         else if (VARIANT == 4)
         {
-            // small scenes (node table in LDS): while-while; big scenes in flight (and their diagnostic build, whose counts go
-            // with that line): one step per trip by majority.  Both carry unfinished walks over.
-            bvh_advance<STATS, true, ((R1_TP_MAJORITY || !LN) && (STATS || !LAT)), LN>(A.scene, p.o, p.d, tv, s_trav, tid, (uint32_t)__popcll(live_now), wstat, lnodes, top);
+            // while-while with carry-over (the voting walk, MAJORITY = true, is an option of the build: R1_TP_MAJORITY)
+            bvh_advance<STATS, true, (R1_TP_MAJORITY && (STATS || !LAT)), LN>(A.scene, p.o, p.d, tv, s_trav, tid, (uint32_t)__popcll(live_now), wstat, lnodes, top);
             ready = alive && tv.cur == R1_BVH_DONE;
             if (tv.best_id != 0xFFFFFFFFu)
                 t_hit = tv.best, hit = (int)tv.best_id;
