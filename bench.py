@@ -1,18 +1,22 @@
 #!/usr/bin/env python3
 """bench.py — mrays/s of the step13 hot path on N MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py                              # N = 1
+    python bench.py --gpus N                     # launches itself: N fresh rank processes (torch.distributed.run), RCCL
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W          # the driver's form: the same ranks
+    python bench.py --gpus N --multi inproc      # ONE process, N GPUs: r1_multi_* (ncclCommInitAll), one frame at a time
 
-A "step" is one full frame of the workload: every rank traces + resolves the tiles it owns
-(tile t -> rank t % N, include/rays1.h r1_params.shard), then the dense per-rank tile blocks
-(each with its 8-byte ray count appended) are all-gathered with RCCL (torch.distributed "nccl")
-— ONE collective per frame — and the row-major image is assembled on every rank.  At N = 1 there is no collective.  The frame is
-fixed (BASELINE: large scene, 1200x800x10 spp), so scaling is STRONG.  Inputs (sphere tables,
-camera) are resident in HBM before the timed region; the image stays in HBM (the
-PCIe-inclusive rate of the host-returning r1_render() is reported separately, never as
-`value`).  Data is synthetic by construction: the scenes are code, not files.
+A "step" is one full frame of the workload, from dispatch to PIXELS AND RAY COUNT ON THE HOST — the span the
+reference's Timer covers (rayweek1.cpp:848 -> :891): every rank traces + resolves the tiles it owns (tile t -> rank
+t % N, include/rays1.h r1_params.shard); at N > 1 the per-rank records (dense tile block + 8-byte ray count) are
+all-gathered with RCCL (torch.distributed "nccl") — ONE collective per frame — and assembled; then the row-major image
+and the frame's ray count are copied into page-locked host memory on the frame's own stream.  Several frames are in
+flight (one stream + context + host buffer each), and the timed region ends when every frame's copy has landed.
+The frame is fixed (BASELINE: large scene, 1200x800x10 spp), so scaling is STRONG.  Inputs (sphere tables, camera)
+are resident in HBM before the timed region.  `value_device_resident` is the same run without the copies to the host
+(round 2's headline); `value_dispatch_to_host` is ONE synchronous frame at a time through r1_render() — what the
+drop-in's benchmark() prints.  Data is synthetic by construction: the scenes are code, not files.
 """
 import argparse
 import json
@@ -27,6 +31,16 @@ sys.path.insert(0, ROOT)
 SCENE_KIND = {"small": 0, "medium": 1, "large": 2, "grid": 3}
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_VECTOR_PEAK_TF = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
+VALU_ISSUE_PEAK_T = 1024 * 2.4e9 / 2 / 1e12  # wave-instructions/s: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles
+
+# Frames in flight only overlap when their streams sit on different hardware queues; the ROCm default is 4.
+# Measured on one MI355X: one queue per frame in flight is the optimum (16 in flight on 16 queues
+# 1.18 ms per frame; 12 on 16: 1.77; 12 on 12: 1.20), 20 on 20 is 3 % better over a short run, and at 24 queues the
+# process runs out of hardware queues (10-24 Grays/s).  Ranks that also run RCCL (its stream needs a queue of its own)
+# therefore keep 16 frames in flight on 18 queues; one process driving N GPUs in-process runs one frame at a time.
+INFLIGHT_SINGLE, QUEUES_SINGLE = 20, 20
+INFLIGHT_RANK, QUEUES_RANK = 16, 18
+QUEUES_CLIFF = 24
 
 
 def cpu_model():
@@ -71,10 +85,15 @@ def cpu_baseline(scene, w, h, spp):
         rec = rec[1:]  # first run pays page faults / thread start
         rays = sum(r["rays"] for r in rec)
         secs = sum(r["seconds"] for r in rec)
-        return {"value": rays / secs / 1e6, "unit": "mrays/s", "cores": rec[0]["threads"], "kind": "reference", "cpu_model": cpu_model(),
+        threads = rec[0]["threads"]
+        tiles = ((w + 31) // 32) * ((h + 31) // 32)
+        return {"value": rays / secs / 1e6, "unit": "mrays/s", "cores": threads, "kind": "reference", "cpu_model": cpu_model(),
                 "sample": f"{scene} {w}x{h}x{spp}: {len(rec)} frames through the reference's TileRenderScheduler/render_tile "
                           f"({os.path.basename(binary)}: flags of reference bench.py:175 with "
-                          f"{'-march=x86-64-v3' if 'avx2' in os.path.basename(binary) else '-march=native of the build container'}), {secs:.1f} s"}
+                          f"{'-march=x86-64-v3' if 'avx2' in os.path.basename(binary) else '-march=native of the build container'}), {secs:.1f} s",
+                "note": f"the reference as it is: {threads} threads are spawned and joined for every {secs / len(rec) * 1e3:.0f} ms frame and share "
+                        f"{tiles} tiles ({tiles / max(threads, 1):.1f} per thread), so at this frame size the number is mostly thread start-up "
+                        "and imbalance, not the sweep (reported, not optimised against)"}
     # port: the oracle's restatement of the threaded path
     import rays1bench_amd as r1
     sc = r1.Scene(SCENE_KIND[scene], w, h)
@@ -146,7 +165,6 @@ FLOP_NODE, FLOP_SPHERE, FLOP_GROUP = 55.0, 16.0, 15.0
 def measure_work(rend, p, info, binding):
     """Counts what one launch of the timed kernel executes: a synchronous frame through the
     diagnostic build of the same kernel (same samples; tools/bvh_stats.py, tools/kernel_stats.py)."""
-    import ctypes as C
     import numpy as np
     stats_variant = binding.VARIANT_BVH_STATS if info["kernel"] == 4 else binding.VARIANT_STATS
     q = binding.Params.from_buffer_copy(p)
@@ -156,8 +174,8 @@ def measure_work(rend, p, info, binding):
     st = rend.last_stats()
     it = max(st["wave_iterations"], 1)
     if info["kernel"] == 4:
-        # slot "cycles_pass1" of the tree build: sphere-pair tests (low 32 bits) | leaf trips summed over lanes << 32
-        visits, pairs, leaf_lane_trips = st["candidates"], st["cycles_pass1"] & 0xFFFFFFFF, st["cycles_pass1"] >> 32
+        # 64-bit counters each: [9] node visits, [5] ("cycles_pass1" of the sweep build) sphere-pair tests, [14] leaf trips x lanes
+        visits, pairs, leaf_lane_trips = st["candidates"], st["cycles_pass1"], st["leaf_lane_trips"]
         return {"source": "R1_VARIANT_BVH_STATS frame (same samples as the timed kernel)", "rays_per_launch": rays,
                 "node_visits_per_ray": visits / rays, "sphere_pair_tests_per_ray": pairs / rays,
                 "flop_per_node_visit": FLOP_NODE, "flop_per_sphere_pair_test": 2 * FLOP_SPHERE,
@@ -174,7 +192,7 @@ def measure_work(rend, p, info, binding):
             "lane_utilisation": {"at_hit_test": st["alive_lanes"] / (64.0 * it)}}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
@@ -186,54 +204,166 @@ def main():
     ap.add_argument("--grid", default="400x250", help="with --scene grid: small-sphere lattice WxH (BASELINE config 5: 400x250)")
     ap.add_argument("--seed", type=int, default=10001)
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--multi", default="procs", choices=["procs", "inproc"],
+                    help="N > 1: `procs` = one rank process per GPU, torch.distributed + RCCL (bench.py starts the ranks itself when it "
+                         "was not started by torch.distributed.run); `inproc` = this one process drives all N GPUs through "
+                         "r1_multi_* (ncclCommInitAll + one ncclAllGather per frame), one synchronous frame at a time")
     ap.add_argument("--inflight", type=int, default=0,
                     help="frames in flight, each on its own stream + context workspace: later frames' workgroups fill "
                          "the CUs that a frame's last long bounce chains leave idle (1 = one frame at a time; "
-                         "0 = default: 20 on one GPU, 16 per rank when RCCL needs hardware queues of its own)")
+                         f"0 = default: {INFLIGHT_SINGLE} on one GPU, {INFLIGHT_RANK} per rank when RCCL needs hardware queues of its own)")
+    ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this run (0 = the mode's measured default)")
     ap.add_argument("--emulate-shards", type=int, default=0,
                     help="tuning aid: render only shard 0 of K on one GPU, no collective (per-rank load of a K-GPU run)")
+    ap.add_argument("--rccl-selftest", action="store_true",
+                    help="with --emulate-shards K on one GPU: also run the rank path's RCCL all-gather per frame through a ONE-rank "
+                         "communicator (the collective's launch cost next to a 1/K frame; the data does not leave the GPU)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--check", action="store_true",
-                    help="after the timed region compare the gathered + assembled image and ray count with an unsharded render")
+                    help="after the timed region compare the image and ray count that landed on the host with an unsharded render")
     ap.add_argument("--pixel-mode", action="store_true",
                     help="r1_set_pixel_mode: lanes own pixels, 3 B/pixel written, no per-sample workspace, no resolve launch (~10 %% slower)")
+    ap.add_argument("--no-host-copy", action="store_true", help="`value` = frames left in HBM (round 2's headline mode), no copies to the host")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (device-resident run, exhaustive sweep, r1_render span)")
+    ap.add_argument("--lib", default="", help="another build of librays1.so (e.g. rays1bench_amd/lib/librays1_tuning.so, `make tuning`: "
+                                              "the build that reads the R1_* tuning knobs); default: the shipped library")
     ap.add_argument("--cpu-table", action="store_true",
                     help="also time the reference's step13 (all threads / 1 thread) on the three scenes and the step1 port "
                          "on the host cores (cpu_baseline.table; adds ~30 s)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    # Frames in flight only overlap when their streams sit on different hardware queues; the
-    # ROCm default is 4 (measured: 16 queues + 16 frames in flight reach 98 % / 91 % of the ideal
-    # per-rank frame time at 1/2/4 and 8 shards, 4 queues 78 % / 66 %).  Must be set before HIP starts.
-    # One queue per frame in flight: streams that share a queue serialise, and spare queues hurt too
-    # (measured: 16 in flight on 16 queues 1.18 ms per frame; 12 on 16: 1.77; 12 on 12: 1.20; 24 on 24: 1.53).
-    # 20 in flight on 20 queues: the driver's short run (20 steps) 26.3 -> 27.1 Grays/s, a long run unchanged (29.6); 24 on 24
-    # collapses (10-24 Grays/s, the process runs out of hardware queues), so ranks that also run RCCL stay at 16.
-    if args.inflight <= 0:
-        args.inflight = 20 if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.emulate_shards <= 1 else 16
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(1, min(args.inflight, 24))))
-    import torch
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH processes with torch.distributed.run
+    (the form the driver uses) and pass their output and exit code through.  This parent never imports torch and never
+    touches HIP — nothing that has initialised the GPU is ever exec'd or forked."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(cmd, env=env, cwd=os.getcwd())
+    return proc.returncode
+
+
+def set_hw_queues(args, default):
+    q = args.hw_queues if args.hw_queues > 0 else default
+    q = max(1, min(q, QUEUES_CLIFF - 1))
+    os.environ["GPU_MAX_HW_QUEUES"] = str(q)  # explicit per mode; must be set before HIP starts
+    return q
+
+
+def workload_config(args, info, n, rays_per_step):
+    w, h, spp = args.width, args.height, args.spp
+    return {"workload": f"{args.scene} scene ({info['spheres_active']} spheres, N_pad {info['spheres_padded']}), {w}x{h}, {spp} spp, "
+                        f"max 50 bounces, seed {args.seed}",
+            "rays_per_step": rays_per_step, "tiles": "32x32, tile t -> rank t % N"}
+
+
+def run_inproc(args):
+    """ONE process, N GPUs: r1_multi_* — tile split, ncclCommInitAll, one ncclAllGather per frame, device 0 assembles and
+    copies to the host (csrc/r1_multi.cpp; rayweek1.cpp:869-877: one call renders on all workers).  One synchronous
+    frame per step, so this mode shows the latency-mode number, never the frames-in-flight one."""
+    n = args.gpus
+    set_hw_queues(args, 4)
+    import numpy as np
+    import torch  # only for the contract's synchronize; r1_multi brings its own RCCL binding
     import rays1bench_amd as r1
-    from rays1bench_amd import binding, sharding
+    from rays1bench_amd import binding
+    if args.lib:
+        binding.set_lib_path(args.lib)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product has no CPU fallback)")
+    if torch.cuda.device_count() < n:
+        raise SystemExit(f"--multi inproc --gpus {n}: only {torch.cuda.device_count()} devices visible")
+    w, h, spp = args.width, args.height, args.spp
+    gw, gh = (int(v) for v in args.grid.split("x")) if args.scene == "grid" else (0, 0)
+    scene = r1.Scene(SCENE_KIND[args.scene], w, h, gw, gh)
+    multi = binding.MultiRenderer(list(range(n)))
+    multi.set_scene(scene)
+    p = r1.make_params(w, h, spp, args.seed, variant=args.variant)
+    img = np.zeros((h, w, 3), np.uint8)
 
+    def step():
+        return multi.render_into(p, img)
+
+    def fence():
+        for d in range(n):
+            torch.cuda.synchronize(d)
+
+    for _ in range(max(args.warmup, 1)):
+        rays_per_step, _ = step()
+    fence()
+    t0 = time.perf_counter()
+    dev_s = 0.0
+    for _ in range(args.steps):
+        rays, s = step()
+        dev_s += s
+    fence()
+    elapsed = time.perf_counter() - t0
+    info = multi.info()
+    check = None
+    if args.check:
+        rend = r1.Renderer(0)
+        rend.set_scene(scene)
+        ref = np.zeros((h, w, 3), np.uint8)
+        ref_rays, _ = rend.render_into(r1.make_params(w, h, spp, args.seed, variant=args.variant), ref)
+        check = bool(ref.tobytes() == img.tobytes() and ref_rays == rays)
+        rend.close()
+    cfg = workload_config(args, info["first_device"], n, rays_per_step)
+    cfg.update({"parallelism": f"tile-split x{n}, ONE process (r1_multi: ncclCommInitAll, one ncclAllGather per frame, RCCL {info['rccl_version']})",
+                "value_mode": "one synchronous frame at a time through r1_multi_render: dispatch -> pixels + ray count on the host "
+                              "(rayweek1.cpp:848 -> :891); latency-mode kernels, no frames in flight",
+                "frames_in_flight": 1, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                "workgroups": info["first_device"]["blocks"], "threads_per_workgroup": info["first_device"]["threads_per_block"],
+                "device_ms_per_step": dev_s / args.steps * 1e3})
+    out = {"metric": f"mrays/s on '{args.scene}' scene {w}x{h}x{spp}spp", "value": rays_per_step * args.steps / elapsed / 1e6, "unit": "mrays/s",
+           "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": cfg,
+           "roofline": {"bound": "valu", "peak": FP32_VECTOR_PEAK_TF, "unit": "TFLOP/s", "achieved": None, "frac": None, "traffic": None,
+                        "note": "the in-process mode reports the latency of the N-GPU frame; the kernel's roofline is measured by the default mode"}}
+    if check is not None:
+        out["check"] = check
+    print(json.dumps(out), flush=True)
+    multi.close()
+    return 0
+
+
+def run_ranks(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    n = args.gpus
-    if world != n:
-        if world == 1 and n > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        n = world
+    n = world
+    uses_rccl = (n > 1 and args.backend == "nccl") or args.rccl_selftest
+    if args.inflight <= 0:
+        args.inflight = INFLIGHT_RANK if (n > 1 or args.emulate_shards > 1) else INFLIGHT_SINGLE
+    extra = QUEUES_RANK - INFLIGHT_RANK if uses_rccl else 0
+    args.inflight = max(1, min(args.inflight, QUEUES_CLIFF - 1 - extra))  # frames' queues + RCCL's stay under the cliff
+    set_hw_queues(args, args.inflight + extra)
+    import numpy as np
+    import torch
+    import rays1bench_amd as r1
+    from rays1bench_amd import binding, sharding
+    if args.lib:
+        binding.set_lib_path(args.lib)
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product has no CPU fallback)")
     if os.environ.get("R1_BENCH_DEVICE"):  # rehearsal: several ranks on one GPU (gloo backend)
         local_rank = int(os.environ["R1_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dist = None
-    if n > 1:
+    if n > 1 or args.rccl_selftest:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if n == 1:
+            os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend != "nccl":
             dist.init_process_group(args.backend, rank=rank, world_size=n)
         else:
@@ -244,16 +374,18 @@ def main():
 
     w, h, spp = args.width, args.height, args.spp
     dev = torch.device("cuda", local_rank)
-    p = r1.make_params(w, h, spp, args.seed, shard=rank, num_shards=n, variant=args.variant)
-    if args.emulate_shards > 1 and n == 1:
-        p = r1.make_params(w, h, spp, args.seed, shard=0, num_shards=args.emulate_shards, variant=args.variant)
-    block_bytes = binding.shard_block_bytes(p)
-
     shards = max(n, args.emulate_shards, 1)
-    record_bytes = block_bytes + sharding.RECORD_TRAILER  # tile block + uint64 ray count: one all-gather per frame
+    sharded = shards > 1
+    p = r1.make_params(w, h, spp, args.seed, shard=rank if n > 1 else 0, num_shards=shards, variant=args.variant)
+    block_bytes = binding.shard_block_bytes(p)
+    record_bytes = binding.shard_record_bytes(p)  # tile block (padded to 8 bytes) + uint64 ray count: one all-gather per frame
+    trailer = record_bytes - sharding.RECORD_TRAILER
+    img_bytes = w * h * 3
+    img_pad = (img_bytes + 7) & ~7
+    host_copy = [not args.no_host_copy]
 
     class Slot:
-        """One frame in flight: its own context (stream-ordered workspace), buffers and stream."""
+        """One frame in flight: its own context (stream-ordered workspace), stream, device buffers and page-locked host frame."""
 
         def __init__(self):
             self.rend = r1.Renderer(local_rank)
@@ -262,26 +394,63 @@ def main():
             self.rend.set_scene(self.scene)
             if args.pixel_mode:
                 self.rend.set_pixel_mode(True)
-            self.record = torch.zeros(record_bytes, dtype=torch.uint8, device=dev)
-            self.gathered = torch.zeros(shards * record_bytes, dtype=torch.uint8, device=dev) if shards > 1 else self.record
-            self.image = torch.zeros((h, w, 3), dtype=torch.uint8, device=dev)
+            self.host = binding.HostFrame(w, h)  # pixels + ray count land here
             self.stream = torch.cuda.Stream(device=dev)
+            if sharded or args.pixel_mode:
+                self.record = torch.zeros(record_bytes, dtype=torch.uint8, device=dev)
+                self.gathered = torch.zeros(n * record_bytes, dtype=torch.uint8, device=dev) if n > 1 else self.record
+                # row-major image with the frame's ray count behind it: one copy brings both to the host
+                self.image = torch.zeros(img_pad + 8, dtype=torch.uint8, device=dev)
 
         def step(self):
+            sp = self.stream.cuda_stream
+            if not (sharded or args.pixel_mode):
+                # whole frame on this GPU: trace + resolve straight into the row-major image, then image + count -> host
+                if host_copy[0]:
+                    self.rend.render_async(p, self.host, sp)
+                else:
+                    self.rend.render_frame_device(p, sp)
+                return
             with torch.cuda.stream(self.stream):
-                sp = self.stream.cuda_stream
-                self.rend.render_shard_device(p, self.record.data_ptr(), self.record.data_ptr() + block_bytes, sp)
-                if n > 1:
-                    sharding.gather_records(dist, self.record, self.gathered)
-                self.rend.assemble_device_strided(p, self.gathered.data_ptr(), record_bytes, self.image.data_ptr(), sp)
-
-        def local_rays(self):
-            return int(self.record[block_bytes:].view(torch.int64).item())
+                self.rend.render_shard_device(p, self.record.data_ptr(), self.record.data_ptr() + trailer, sp)
+                if dist is not None and (n > 1 or args.rccl_selftest):
+                    if n > 1:
+                        sharding.gather_records(dist, self.record, self.gathered)
+                    else:
+                        dist.all_gather_into_tensor(self.selftest, self.record)
+                if n > 1 or not sharded:
+                    self.rend.assemble_device_records(p, self.gathered.data_ptr(), self.image.data_ptr(), self.image.data_ptr() + img_pad, sp)
+                    if host_copy[0]:
+                        self.host_t.copy_(self.image, non_blocking=True)
+                elif host_copy[0]:
+                    # emulated rank of a K-GPU run: its own record stands in for the gathered image (same bytes per frame / K)
+                    self.host_t[:record_bytes].copy_(self.record, non_blocking=True)
 
         def frame_rays(self):
-            return sharding.total_rays(self.gathered, shards) if n > 1 else self.local_rays()
+            """Whole-frame ray count as it landed (host) or as the device holds it."""
+            torch.cuda.synchronize()
+            if not (sharded or args.pixel_mode):
+                if not host_copy[0]:  # device-resident run: bring one frame home to read its count
+                    self.rend.render_async(p, self.host, self.stream.cuda_stream)
+                    torch.cuda.synchronize()
+                return self.host.rays
+            if n > 1 or not sharded:
+                return int(self.image[img_pad:].view(torch.int64).item())
+            return int(self.record[trailer:].view(torch.int64).item())
+
+        def local_rays(self):
+            torch.cuda.synchronize()
+            if not (sharded or args.pixel_mode):
+                return self.frame_rays()
+            return int(self.record[trailer:].view(torch.int64).item())
 
     slots = [Slot() for _ in range(max(1, args.inflight))]
+    for sl in slots:
+        if sharded or args.pixel_mode:
+            # torch view of the slot's page-locked host frame (r1_host_alloc): target of the non-blocking copies
+            sl.host_t = torch.from_numpy(sl.host._all)
+            if args.rccl_selftest and n == 1:
+                sl.selftest = torch.zeros(record_bytes, dtype=torch.uint8, device=dev)
     rend = slots[0].rend
     counter = [0]
 
@@ -295,54 +464,87 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # setup, not warm-up: one frame through every slot so that its workspace (sample records,
-    # event ring) is allocated before anything is timed, whatever --warmup is
-    for sl in slots:
-        sl.step()
-    fence()
+    def timed(steps, with_events=False):
+        """Time EXACTLY `steps` steps between two fences; max over ranks.  Returns (elapsed, submit, events)."""
+        if with_events:
+            for sl in slots:
+                sl.rend.timing_begin(steps // len(slots) + 2)  # frames this slot will carry
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        submit = time.perf_counter() - t0  # host time to enqueue the frames (must stay below `elapsed`)
+        fence()
+        elapsed = time.perf_counter() - t0
+        ev = None
+        if with_events:
+            trace_ms, total_ms, frames = 0.0, 0.0, 0
+            for sl in slots:
+                a, b, c = sl.rend.timing_end()
+                trace_ms, total_ms, frames = trace_ms + a, total_ms + b, frames + c
+            ev = (trace_ms, total_ms, frames)
+        if n > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, submit, ev
+
+    # setup, not warm-up: frames through every slot so that its workspace (sample records, event ring, page-locked
+    # frame) is allocated before anything is timed, whatever --warmup is.  Two passes: the HIP runtime creates its
+    # hardware queues lazily, ~7 ms each, during the first ~40 submissions on 20 streams (tools/submit_times.py:
+    # five such stalls in the first pass, three in the second, none afterwards).
+    for _ in range(2):
+        for sl in slots:
+            sl.step()
+        fence()
     for _ in range(args.warmup):
         step()
     fence()
     slots[0].step()
-    torch.cuda.synchronize()
-    rays_per_step = slots[0].frame_rays()  # whole frame: the sum of the gathered trailers
+    rays_per_step = slots[0].frame_rays()  # whole frame: the count that landed on the host
+    if sharded and n == 1:
+        rays_per_step = slots[0].local_rays()  # emulated rank: its share only
 
-    for sl in slots:
-        sl.rend.timing_begin(args.steps // len(slots) + 2)  # frames this slot will carry
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    submit = time.perf_counter() - t0  # host time to enqueue the frames (must stay below `elapsed`)
-    fence()
-    elapsed = time.perf_counter() - t0
-    trace_ms_sum, total_ms_sum, frames = 0.0, 0.0, 0
-    for sl in slots:
-        a, b, c = sl.rend.timing_end()
-        trace_ms_sum, total_ms_sum, frames = trace_ms_sum + a, total_ms_sum + b, frames + c
-    if n > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
+    elapsed, submit, (trace_ms_sum, total_ms_sum, frames) = timed(args.steps, with_events=True)
     value = rays_per_step * args.steps / elapsed / 1e6
     info = rend.launch_info()
+    local_rays = slots[0].local_rays()  # this rank's rays: the work of ITS kernel launches
+
+    check = None
+    if args.check and not (sharded and n == 1):
+        torch.cuda.synchronize()
+        if sharded or args.pixel_mode:
+            got = (slots[0].host._all[:img_bytes] if host_copy[0] else slots[0].image[:img_bytes].cpu().numpy()).tobytes()
+        else:
+            slots[0].frame_rays()  # (device-resident run: brings one frame home)
+            got = slots[0].host.image.tobytes()
+        ref = np.zeros((h, w, 3), np.uint8)
+        ref_rays, _ = rend.render_into(r1.make_params(w, h, spp, args.seed, variant=args.variant), ref)
+        check = bool(got == ref.tobytes() and rays_per_step == ref_rays)
+
+    # ---- secondary measurements (rank 0's line only; every rank takes part in the timed regions) ----
+    resident = None
+    if host_copy[0] and not args.no_extras:
+        # the same frames left in HBM: what the copies to the host cost
+        host_copy[0] = False
+        for _ in range(len(slots)):
+            step()
+        steps2 = max(len(slots), args.steps // 2)
+        e2, _, _ = timed(steps2)
+        resident = {"value": rays_per_step * steps2 / e2 / 1e6, "unit": "mrays/s", "steps": steps2, "ms_per_step": e2 / steps2 * 1e3,
+                    "mode": f"{len(slots)} frames in flight, image and ray count left in HBM (round 2's headline mode)"}
+        host_copy[0] = True
 
     # The same workload through the exhaustive sweep (the reference's algorithm: every ray against
     # every sphere), when `value` came from the box tree: reported beside it, never instead of it.
     sweep_line = None
-    if n == 1 and args.variant == 0 and info["kernel"] == 4 and args.emulate_shards <= 1 and info["spheres_active"] <= 1023:
+    if n == 1 and args.variant == 0 and info["kernel"] == 4 and not sharded and info["spheres_active"] <= 1023 and not args.no_extras:
         p_main = p
         p = r1.make_params(w, h, spp, args.seed, shard=0, num_shards=1, variant=binding.VARIANT_PREFILTER)
         sweep_steps = max(len(slots), args.steps // 2)
         for _ in range(len(slots)):
             step()
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(sweep_steps):
-            step()
-        fence()
-        sweep_elapsed = time.perf_counter() - t1
+        sweep_elapsed, _, _ = timed(sweep_steps)
         sweep_rate = rays_per_step * sweep_steps / sweep_elapsed
         sweep_line = {"value": sweep_rate / 1e6, "unit": "mrays/s", "steps": sweep_steps,
                       "ms_per_step": sweep_elapsed / sweep_steps * 1e3,
@@ -354,24 +556,11 @@ def main():
                                   "per ray) at this kernel's ray rate.  Reference-equivalent, not executed, work: the kernel tests "
                                   "groups of <= 4 spheres from SGPRs, so these figures may exceed the hardware peaks (8 TB/s, 157.3 TFLOP/s)"},
                       "kernel": "grouped exhaustive sweep (R1_VARIANT_PREFILTER): every ray tested against every sphere group, "
-                                "as the reference's Hitable::hit does; same pixels"}
+                                "as the reference's Hitable::hit does; same pixels; pixels + count on the host like `value`"}
         p = p_main
         slots[0].step()  # leave launch_info / images describing the main kernel
         torch.cuda.synchronize()
         info = rend.launch_info()
-
-    # local rays of this rank for the roofline of ITS kernel launches
-    local_rays = slots[0].local_rays()
-
-    check = None
-    if args.check:
-        import numpy as np
-        torch.cuda.synchronize()
-        got = slots[0].image.cpu().numpy()
-        got_rays = rays_per_step
-        ref = np.zeros((h, w, 3), np.uint8)
-        ref_rays, _ = rend.render_into(r1.make_params(w, h, spp, args.seed, variant=args.variant), ref)
-        check = bool(got.tobytes() == ref.tobytes() and got_rays == ref_rays)
 
     # ---- what the timed kernel executes (measured, outside the timed region): one synchronous frame
     # through the diagnostic build of the same kernel (R1_VARIANT_*_STATS: same samples, plus counters)
@@ -383,88 +572,99 @@ def main():
             work = {"error": str(e)}
 
     if rank == 0:
-        n_pad = info["spheres_padded"]
         is_tree = info["kernel"] in (4, 5, 6)
         kernel_name = {1: "reference-form exhaustive sweep", 2: "grouped exhaustive sweep" + (" (LDS-tiled)" if info["spheres_active"] > 1023 else ""),
                        3: "grouped exhaustive sweep + counters", 4: "box tree (R1_VARIANT_BVH)", 5: "box tree + counters",
                        6: "wavefront: generate / intersect / shade kernels, box tree (comparison build)"}[info["kernel"]]
         kernel_s = trace_ms_sum / max(frames, 1) * 1e-3  # average launch duration, HIP events on the stream of each launch
         overlap = trace_ms_sum * 1e-3 / elapsed           # launches of different frames overlap (frames in flight)
-        traffic, traffic_source, valu_instr, valu_source, valu_lanes = None, None, None, None, None
+        traffic, traffic_source, valu_instr, valu_source, valu_lanes, valu_busy = None, None, None, None, None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath) and info["kernel"] != 6:
             try:
                 tj = json.load(open(tpath))
-                if tj.get("workload") == f"{args.scene} {w}x{h}x{spp}" and n == 1 and tj.get("kernel_variant") == info["kernel"]:
+                if tj.get("workload") == f"{args.scene} {w}x{h}x{spp}" and n == 1 and not sharded and tj.get("kernel_variant") == info["kernel"]:
                     traffic = tj.get("hbm_bytes_per_launch")
                     traffic_source = f"profiles/pmc_traffic.json: {tj.get('source', 'rocprofv3 --pmc passes')} (not measured by this run)"
                     valu_instr = tj.get("valu_wave_instructions_per_launch")
                     valu_lanes = tj.get("valu_active_lane_fraction")
+                    valu_busy = tj.get("valu_busy_fraction")
                     valu_source = f"{tj.get('valu_source', 'profiles/')} (not measured by this run)"
             except Exception:
                 traffic = None
         flop = work.get("flop_per_launch") if work else None
+        agg = (flop * frames / elapsed / 1e12) if flop else None
         roofline = {
             # No dense contraction on this path (no MFMA) and the tables are cache resident, so neither of
             # the contract's two roofs binds: the roof is fp32 VECTOR issue.  `achieved` counts the flop the
-            # launch EXECUTES in its hit tests (measured counts x flop per unit, below) — never the
-            # reference-equivalent 16 B x N_pad model (that figure lives in `exhaustive_sweep`).
+            # launches EXECUTE in their hit tests (measured counts x flop per unit, below) — never the
+            # reference-equivalent 16 B x N_pad model (that figure lives in `exhaustive_sweep`) — over the WALL time of
+            # the timed region: with frames in flight the launches overlap, so a launch's own duration is not its share
+            # of the machine (that per-launch figure is kept under `per_launch`).
             "bound": "valu", "peak": FP32_VECTOR_PEAK_TF, "unit": "TFLOP/s",
-            "achieved": (flop / kernel_s / 1e12) if flop else None,
-            "frac": (flop / kernel_s / 1e12 / FP32_VECTOR_PEAK_TF) if flop else None,
+            "achieved": agg,
+            "frac": (agg / FP32_VECTOR_PEAK_TF) if agg else None,
             "traffic": traffic, "traffic_source": traffic_source,
             "kernel": "r1_trace_kernel" if info["kernel"] != 6 else "r1_wf_generate + 51 x (r1_wf_intersect, r1_wf_shade)",
-            "kernel_ms": kernel_s * 1e3,
             "flop_per_launch": flop,
             "work": work,
-            # with several frames in flight the launches overlap: `achieved` is per launch as the contract
-            # defines it (flop per launch / average launch duration); x launch_overlap = what the chip sustains
             "launch_overlap": overlap,
-            "achieved_aggregate": (flop * frames / elapsed / 1e12) if flop else None,
-            "frac_aggregate": (flop * frames / elapsed / 1e12 / FP32_VECTOR_PEAK_TF) if flop else None,
+            "per_launch": {"kernel_ms": kernel_s * 1e3,  # HIP events around each launch, on its stream; rocprofv3's average agrees (profiles/)
+                           "achieved": (flop / kernel_s / 1e12) if flop else None,
+                           "frac": (flop / kernel_s / 1e12 / FP32_VECTOR_PEAK_TF) if flop else None,
+                           "note": "flop per launch / that launch's own duration: under launch_overlap-deep overlap a launch only has a "
+                                   "share of the chip, so this is a lower bound by that factor, not a utilisation"},
             # what binds the kernel: VALU wave-instructions issued (PMC) against one per two cycles per SIMD
             "valu_issue": {"wave_instructions_per_launch": valu_instr, "source": valu_source,
                            "active_lane_fraction": valu_lanes,  # SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): lanes doing work per issued instruction
-                           "peak": 1024 * 2.4e9 / 2 / 1e12, "unit": "T wave-instructions/s (256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles)",
-                           "achieved_aggregate": (valu_instr * frames / elapsed / 1e12) if valu_instr else None,
-                           "frac_aggregate": (valu_instr * frames / elapsed / 1e12 / (1024 * 2.4e9 / 2 / 1e12)) if valu_instr else None,
+                           "busy_fraction": valu_busy,          # SQ_ACTIVE_INST_VALU x 4 / (SQ_BUSY_CYCLES per SIMD): measured with the frames in flight
+                           "peak": VALU_ISSUE_PEAK_T, "unit": "T wave-instructions/s (256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles)",
+                           "achieved": (valu_instr * frames / elapsed / 1e12) if valu_instr else None,
+                           "frac": (valu_instr * frames / elapsed / 1e12 / VALU_ISSUE_PEAK_T) if valu_instr else None,
                            "note": "the instructions of this kernel issue in 2.7 (fp32 add / mul / fma) to 4.4 cycles (min / max / compare / "
                                    "select / convert): profiles/r02/isa_issue_costs.txt, so ~0.6 of the 2-cycle peak is a busy pipe"},
             "hbm": {"peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "achieved": (traffic / kernel_s / 1e9) if traffic else None,
-                    "achieved_aggregate": (traffic * frames / elapsed / 1e9) if traffic else None,
-                    "frac_aggregate": (traffic * frames / elapsed / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                    "note": "measured HBM bytes per launch (PMC) / time: the sample records and the image; sphere and node tables stay in L1/L2"},
-            "note": "executed hit-test flop / launch duration / fp32 vector peak (157.3 TFLOP/s).  Low by construction: the count "
+                    "achieved": (traffic * frames / elapsed / 1e9) if traffic else None,
+                    "frac": (traffic * frames / elapsed / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                    "note": "measured HBM bytes per launch (PMC) x frames / wall time: the sample records and the image; sphere and node tables stay in L1/L2"},
+            "note": "executed hit-test flop x frames / wall time / fp32 vector peak (157.3 TFLOP/s).  Low by construction: the count "
                     "leaves out shading, RNG, queue and control instructions, idle lanes of divergent traversals "
-                    "(work.lane_utilisation) and the 4-cycle issue of VOP3 instructions; VALU issue-busy cycles are in "
-                    "profiles/ (DESIGN.md §7).",
+                    "(work.lane_utilisation) and the 4-cycle issue of VOP3 instructions; what binds is `valu_issue`.",
         }
+        cfg = workload_config(args, info, n, rays_per_step)
+        host_mb = (img_bytes + 8) / 1e6 if not (sharded and n == 1) else record_bytes / 1e6
+        cfg.update({
+            "parallelism": f"tile-split x{n}" + (" + one RCCL all-gather per frame (pixels + ray counts)" if n > 1 else ""),
+            "value_mode": (f"{len(slots)} frames in flight (one stream + context each), scene resident in HBM; every frame ends with its "
+                           f"pixels + ray count copied to page-locked HOST memory ({host_mb:.2f} MB per frame) on its own stream, and the timed "
+                           "region ends when all copies have landed (rayweek1.cpp:848 -> :891, pipelined)") if host_copy[0] else
+                          f"{len(slots)} frames in flight (one stream + context each), scene and image resident in HBM",
+            "workgroups": info["blocks"], "threads_per_workgroup": info["threads_per_block"],
+            "frames_in_flight": len(slots), "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+            "host_submit_ms_per_step": submit / args.steps * 1e3,
+            "kernel": kernel_name})
+        if is_tree:
+            cfg["bvh"] = {"nodes": info["bvh_nodes"], "leaves": info["bvh_leaves"], "depth": info["bvh_depth"]}
+        if sharded and n == 1:
+            cfg["emulated_shards"] = shards
+            cfg["local_rays_per_step"] = local_rays
         out = {
             "metric": f"mrays/s on '{args.scene}' scene {w}x{h}x{spp}spp",
             "value": value, "unit": "mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.scene} scene ({info['spheres_active']} spheres, N_pad {n_pad}), {w}x{h}, {spp} spp, "
-                                   f"max 50 bounces, seed {args.seed}",
-                       "rays_per_step": rays_per_step, "tiles": "32x32, tile t -> rank t % N",
-                       "parallelism": f"tile-split x{n}" + (" + one RCCL all-gather per frame (pixels + ray counts)" if n > 1 else ""),
-                       "value_mode": f"{len(slots)} frames in flight (one stream + context each), scene and image resident in HBM",
-                       "workgroups": info["blocks"], "threads_per_workgroup": info["threads_per_block"],
-                       "frames_in_flight": len(slots), "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
-                       "host_submit_ms_per_step": submit / args.steps * 1e3,
-                       "kernel": kernel_name,
-                       **({"bvh": {"nodes": info["bvh_nodes"], "leaves": info["bvh_leaves"], "depth": info["bvh_depth"]}} if is_tree else {})},
+            "config": cfg,
             "roofline": roofline,
         }
+        if resident is not None:
+            out["value_device_resident"] = resident
         if sweep_line is not None:
             out["exhaustive_sweep"] = sweep_line
         if check is not None:
             out["check"] = check
-        if n == 1:
-            # The survey's timer span (rayweek1.cpp:848 -> :891): dispatch -> pixels + ray count on the HOST,
-            # one synchronous frame at a time through r1_render() — what the drop-in benchmark() prints.
-            import numpy as np
+        if n == 1 and not sharded and not args.no_extras:
+            # The survey's timer span (rayweek1.cpp:848 -> :891) for ONE frame the caller waits for, through r1_render() —
+            # what the drop-in benchmark() prints: latency-mode kernels, one frame at a time.
             host = np.zeros((h, w, 3), np.uint8)
             ph = r1.make_params(w, h, spp, args.seed, variant=args.variant)
             rend.render_into(ph, host)
@@ -479,22 +679,38 @@ def main():
                 "value": tot / d2h / 1e6, "unit": "mrays/s", "ms_per_step": d2h / reps * 1e3, "steps": reps,
                 "device_ms_per_step": dev_s / reps * 1e3,
                 "span": "r1_render(): launch -> pixels + ray count on the host (the reference's Timer span, rayweek1.cpp:848 -> :891), "
-                        "one frame at a time, PCIe copy included"}
-            if not args.no_cpu_baseline:
-                try:
-                    out["cpu_baseline"] = cpu_baseline_grid(slots[0].scene, w, h) if args.scene == "grid" else cpu_baseline(args.scene, w, h, spp)
-                except Exception as e:  # the baseline is reported, never required
-                    out["cpu_baseline"] = {"value": None, "unit": "mrays/s", "cores": os.cpu_count(), "kind": "reference",
-                                           "sample": f"failed: {e}"}
-                if args.cpu_table:
-                    out["cpu_baseline"]["table"] = cpu_table(w, h, spp)
+                        "one synchronous frame at a time, PCIe copy included"}
+        if n == 1 and not sharded and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline_grid(slots[0].scene, w, h) if args.scene == "grid" else cpu_baseline(args.scene, w, h, spp)
+            except Exception as e:  # the baseline is reported, never required
+                out["cpu_baseline"] = {"value": None, "unit": "mrays/s", "cores": os.cpu_count(), "kind": "reference",
+                                       "sample": f"failed: {e}"}
+            if args.cpu_table:
+                out["cpu_baseline"]["table"] = cpu_table(w, h, spp)
         print(json.dumps(out), flush=True)
-    if n > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     for sl in slots:
         sl.rend.close()
+        sl.host.close()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.multi == "inproc":
+        return run_inproc(args)
+    world = os.environ.get("WORLD_SIZE")
+    if world is None and args.gpus > 1:
+        return self_launch(args)  # before torch / HIP are touched
+    if world is not None and int(world) != args.gpus:
+        args.gpus = int(world)  # the launcher decides how many ranks there are
+    return run_ranks(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -18,14 +18,11 @@
  * There is NO CPU fallback: without a usable HIP device every compute entry point
  * fails with R1_ENODEVICE.
  *
- * Environment variables.  None is part of the interface.  librays1 reads a few R1_* variables
- * once per process as tuning aids for the measurements under tools/ and profiles/ (launch
- * geometry: R1_SAMPLES_PER_LANE, R1_MIN_BLOCKS, R1_BLOCKS_PER_CU, R1_CHUNK, R1_CHUNK_MIN, R1_NQ,
- * R1_COOP_LANES, R1_TP_MODE; builders of the sweep groups and of the box tree: R1_GROUP_MAX,
- * R1_GROUP_RATIO, R1_BVH_LEAF, R1_BVH_PEEL, R1_BVH_PEEL_RATIO, R1_BVH_PAD_LOCAL, R1_BVH_TOP,
- * R1_BIG_TOP).  They only
- * choose among launch shapes and conservative index layouts that produce the same pixels and
- * ray counts; unset (the shipped defaults) is what every number in DESIGN.md refers to.
+ * Environment variables.  None.  The shipped library never reads the environment: what it computes and how it
+ * launches depends on its arguments only.  (A separate build with -DR1_TUNING, `make -C rays1bench_amd/csrc tuning`
+ * -> lib/librays1_tuning.so, reads R1_* launch-shape and index-layout knobs for the measurements under tools/ and
+ * profiles/; it is loaded explicitly by those scripts, never by the product or its tests, and every knob only chooses
+ * among forms that produce the same pixels and ray counts.)
  */
 #ifndef RAYS1_H
 #define RAYS1_H
@@ -37,7 +34,7 @@
 extern "C" {
 #endif
 
-#define R1_ABI_VERSION 2
+#define R1_ABI_VERSION 3
 
 enum
 {
@@ -126,7 +123,7 @@ enum
                                  box tree chooses the spheres given to the reference's per-sphere test; results
                                  are bit-identical to the exhaustive sweeps   */
     R1_VARIANT_BVH_STATS = 5, /* BVH plus traversal counters (diagnostic; r1_last_stats slots [2] node-loop trips,
-                                 [3] leaf-loop trips, [5] sphere tests, [9] node visits)                          */
+                                 [3] leaf-loop trips, [5] sphere-pair tests, [9] node visits, [14] leaf trips x lanes) */
     R1_VARIANT_WAVEFRONT = 6  /* the same tracer as separate generate / intersect / shade kernels with the paths
                                  and per-level queues in HBM; a comparison build: same pixels,
                                  slower than the megakernel; frames of <= 2^24 sample slots       */
@@ -174,18 +171,38 @@ int r1_render(r1_context *ctx, const r1_params *params, uint8_t *rgb_out, uint64
 int r1_render_samples(r1_context *ctx, const r1_params *params, uint8_t *rgb_out, uint64_t *num_rays_out,
                       float *samples_out);
 
+/* Pipelined form of r1_render — frames in flight whose results land on the HOST.  The reference times
+ * dispatch -> pixels + ray count on the host (rayweek1.cpp:848 -> :891) for ONE frame and waits; a caller that
+ * renders frame after frame (main's `-n` runs, rayweek1.cpp:969-984) can keep several in flight instead: the call
+ * enqueues the frame (throughput kernels: few long-lived waves per frame) on `hip_stream` (a hipStream_t; NULL =
+ * the context's stream) followed by the copies of the row-major image (width*height*3 bytes, as r1_render) and of
+ * the ray count into the caller's buffers, and returns without waiting.  Both buffers are valid once the stream is
+ * idle (r1_sync for the context's stream).  One frame per context at a time: K frames in flight = K contexts.
+ * Whole frames only (num_shards == 1).  Buffers from r1_host_alloc (page-locked) let the copies overlap the other
+ * frames' kernels; pageable memory works, but then every copy waits for its frame.  rgb_out and num_rays_out both
+ * NULL: the frame is rendered and left in the context's device buffers (a measurement aid: what the copies cost). */
+int r1_render_async(r1_context *ctx, const r1_params *params, uint8_t *rgb_out, uint64_t *num_rays_out, void *hip_stream);
+
+/* Page-locked host memory for r1_render_async's outputs (hipHostMalloc / hipHostFree). */
+int r1_host_alloc(size_t bytes, void **out);
+void r1_host_free(void *p);
+
 /* ---- device-resident variants (multi-GPU gather, benchmarks) ----------------------- */
 
 /* Number of tiles / bytes of the dense tile block one shard produces for `params`
  * (every shard's block is padded to the same size so it can be all-gathered). */
 int r1_tile_count(const r1_params *params, int32_t *tiles_total, int32_t *tiles_per_shard);
 size_t r1_shard_block_bytes(const r1_params *params);
+/* Bytes of one shard's gather RECORD: its tile block padded to a multiple of 8, followed by its uint64 ray count
+ * (at r1_shard_record_bytes() - 8, 8-byte aligned for any tile size), so that one all-gather moves pixels and
+ * counts together (the reference sums `out_num_rays` after the join, rayweek1.cpp:809-813). */
+size_t r1_shard_record_bytes(const r1_params *params);
 
 /* Enqueues the render of this shard on the context's stream (or on `hip_stream` if
  * non-NULL, a hipStream_t) and writes DEVICE memory only:
  *   d_block      r1_shard_block_bytes() bytes: tiles_per_shard tiles of tile_h*tile_w*3
  *                bytes each, local tile j = global tile shard + j*num_shards
- *   d_num_rays   one uint64 (overwritten)
+ *   d_num_rays   one uint64 (overwritten); must be 8-byte aligned (R1_EINVAL otherwise)
  * Does not synchronise.  Sized for throughput: meant to be called for several frames in
  * flight (one context + stream per frame in flight). */
 int r1_render_shard_device(r1_context *ctx, const r1_params *params, void *d_block, void *d_num_rays, void *hip_stream);
@@ -213,6 +230,12 @@ int r1_assemble_device(r1_context *ctx, const r1_params *params, const void *d_b
 int r1_assemble_device_strided(r1_context *ctx, const r1_params *params, const void *d_blocks, size_t shard_stride_bytes,
                                void *d_rgb, void *hip_stream);
 
+/* Same for gathered RECORDS (num_shards x r1_shard_record_bytes(), the layout one all-gather returns): scatters the
+ * tile blocks into d_rgb and writes the sum of the shards' ray counts — the join of rayweek1.cpp:809-813 — to
+ * *d_total_rays (device memory, 8-byte aligned; e.g. right behind the image, so that one copy brings both home). */
+int r1_assemble_device_records(r1_context *ctx, const r1_params *params, const void *d_records, void *d_rgb, void *d_total_rays,
+                               void *hip_stream);
+
 /* Blocks until the context's stream is idle. */
 int r1_sync(r1_context *ctx);
 
@@ -231,7 +254,7 @@ int r1_timing_end(r1_context *ctx, double *trace_ms_sum, double *total_ms_sum, i
 /* Diagnostic counters of the last R1_VARIANT_STATS render through the context's own stream:
  * 16 uint64: [0] wave iterations, [1] alive lanes summed over iterations, [2] candidate-loop
  * trips, [3] lanes that overflowed the candidate list, [4..7] cycles in refill / pass 1 /
- * candidate re-test / shade, [8] wave cycles, [9] candidates. */
+ * candidate re-test / shade, [8] wave cycles, [9] candidates, [14] (tree) leaf trips summed over lanes. */
 int r1_last_stats(r1_context *ctx, uint64_t *out16);
 
 /* Per-wave log of the last R1_VARIANT_*_STATS render: 4 uint64 per wave {start, sample queue found

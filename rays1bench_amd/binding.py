@@ -9,6 +9,7 @@ import time
 
 import numpy as np
 
+_lib = None
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
@@ -61,16 +62,27 @@ def make_params(width, height, spp, seed=10001, max_bounces=50, tile_w=32, tile_
     return Params(width, height, spp, max_bounces, seed, tile_w, tile_h, shard, num_shards, variant)
 
 
+_lib_path = os.path.join(LIBDIR, "librays1.so")
+
+
 def lib_path():
-    return os.path.join(LIBDIR, "librays1.so")
+    return _lib_path
+
+
+def set_lib_path(path):
+    """Explicit choice of another build of the library (bench.py --lib, tools/: e.g. lib/librays1_tuning.so, the
+    -DR1_TUNING build that reads the R1_* knobs).  Must be called before the first lib(); nothing is read from the
+    environment here, and the shipped file is never overwritten by an experiment."""
+    global _lib_path
+    if _lib is not None:
+        raise R1Error(R1_EINVAL, "set_lib_path after the library was loaded")
+    _lib_path = os.path.abspath(path)
 
 
 def build(verbose=False):
     """Compiles librays1.so and rayweek1_hip in-tree with hipcc --offload-arch=gfx950."""
     subprocess.check_call(["make", "-C", CSRC] + ([] if verbose else ["-s"]))
 
-
-_lib = None
 
 # every symbol include/rays1.h declares: (name, restype, argtypes)
 _u8p, _f32p, _u64p, _i32p, _dblp = (C.POINTER(t) for t in (C.c_uint8, C.c_float, C.c_uint64, C.c_int32, C.c_double))
@@ -86,6 +98,10 @@ SYMBOLS = [
     ("r1_render_samples", C.c_int, [_ctx, C.POINTER(Params), _u8p, _u64p, _f32p]),
     ("r1_tile_count", C.c_int, [C.POINTER(Params), _i32p, _i32p]),
     ("r1_shard_block_bytes", C.c_size_t, [C.POINTER(Params)]),
+    ("r1_shard_record_bytes", C.c_size_t, [C.POINTER(Params)]),
+    ("r1_render_async", C.c_int, [_ctx, C.POINTER(Params), _u8p, _u64p, C.c_void_p]),
+    ("r1_host_alloc", C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    ("r1_host_free", None, [C.c_void_p]),
     ("r1_render_shard_device", C.c_int, [_ctx, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p]),
     ("r1_set_pixel_mode", C.c_int, [_ctx, C.c_int32]),
     ("r1_render_shard_device_once", C.c_int, [_ctx, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -96,6 +112,7 @@ SYMBOLS = [
     ("r1_multi_info", C.c_int, [C.c_void_p, _i32p, _i32p, C.POINTER(LaunchInfo)]),
     ("r1_assemble_device", C.c_int, [_ctx, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p]),
     ("r1_assemble_device_strided", C.c_int, [_ctx, C.POINTER(Params), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    ("r1_assemble_device_records", C.c_int, [_ctx, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("r1_sync", C.c_int, [_ctx]),
     ("r1_last_timing", C.c_int, [_ctx, _dblp, _dblp]),
     ("r1_timing_begin", C.c_int, [_ctx, C.c_int32]),
@@ -229,6 +246,16 @@ class Renderer:
         _check(lib().r1_render_samples(self._c, C.byref(params), img.ctypes.data_as(_u8p), C.byref(rays), samples.ctypes.data_as(_f32p)))
         return img, int(rays.value), samples
 
+    def render_async(self, params, host_frame, stream_ptr=None):
+        """r1_render_async: enqueue one frame (throughput kernels) whose pixels + ray count land in `host_frame`
+        (a HostFrame) once the stream is idle."""
+        _check(lib().r1_render_async(self._c, C.byref(params), C.cast(host_frame.ptr, _u8p),
+                                     C.cast(host_frame.ptr + host_frame.rays_offset, _u64p), C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def render_frame_device(self, params, stream_ptr=None):
+        """r1_render_async without host buffers: the frame stays in the context's device buffers (what the copies cost)."""
+        _check(lib().r1_render_async(self._c, C.byref(params), None, None, C.c_void_p(stream_ptr) if stream_ptr else None))
+
     def render_shard_device(self, params, d_block_ptr, d_rays_ptr, stream_ptr=None):
         _check(lib().r1_render_shard_device(self._c, C.byref(params), C.c_void_p(d_block_ptr), C.c_void_p(d_rays_ptr),
                                             C.c_void_p(stream_ptr) if stream_ptr else None))
@@ -240,6 +267,10 @@ class Renderer:
     def assemble_device_strided(self, params, d_blocks_ptr, shard_stride_bytes, d_rgb_ptr, stream_ptr=None):
         _check(lib().r1_assemble_device_strided(self._c, C.byref(params), C.c_void_p(d_blocks_ptr), shard_stride_bytes,
                                                 C.c_void_p(d_rgb_ptr), C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def assemble_device_records(self, params, d_records_ptr, d_rgb_ptr, d_total_rays_ptr, stream_ptr=None):
+        _check(lib().r1_assemble_device_records(self._c, C.byref(params), C.c_void_p(d_records_ptr), C.c_void_p(d_rgb_ptr),
+                                                C.c_void_p(d_total_rays_ptr), C.c_void_p(stream_ptr) if stream_ptr else None))
 
     def set_pixel_mode(self, on):
         _check(lib().r1_set_pixel_mode(self._c, 1 if on else 0))
@@ -270,6 +301,7 @@ class Renderer:
         d["longest_wave_cycles"] = int(out[10])
         d["shortest_wave_cycles"] = m - int(out[11])
         d["span_cycles"] = int(out[12]) - (m - int(out[13]))
+        d["leaf_lane_trips"] = int(out[14])  # tree diagnostic build: leaf trips summed over lanes
         return d
 
     def wave_log(self):
@@ -297,6 +329,39 @@ class Renderer:
             pass
 
 
+class HostFrame:
+    """Page-locked host memory (r1_host_alloc) for one frame's results: height x width x 3 pixels followed by an
+    8-byte-aligned uint64 ray count — the target of Renderer.render_async."""
+
+    def __init__(self, width, height):
+        self.nbytes = width * height * 3
+        self.rays_offset = (self.nbytes + 7) & ~7
+        p = C.c_void_p()
+        _check(lib().r1_host_alloc(self.rays_offset + 8, C.byref(p)))
+        self.ptr = p.value
+        buf = (C.c_uint8 * (self.rays_offset + 8)).from_address(self.ptr)
+        self._all = np.frombuffer(buf, np.uint8)
+        self._all[:] = 0
+        self.image = self._all[:self.nbytes].reshape(height, width, 3)
+        self._rays = self._all[self.rays_offset:].view(np.uint64)
+
+    @property
+    def rays(self):
+        return int(self._rays[0])
+
+    def close(self):
+        if self.ptr:
+            self.image = self._rays = self._all = None
+            lib().r1_host_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class MultiRenderer:
     """r1_multi: one process, N GPUs, tile split + one RCCL all-gather per frame (include/rays1.h)."""
 
@@ -313,6 +378,11 @@ class MultiRenderer:
         rays, secs = C.c_uint64(), C.c_double()
         _check(lib().r1_multi_render(self._m, C.byref(params), img.ctypes.data_as(_u8p), C.byref(rays), C.byref(secs)))
         return img, int(rays.value), float(secs.value)
+
+    def render_into(self, params, img):
+        rays, secs = C.c_uint64(), C.c_double()
+        _check(lib().r1_multi_render(self._m, C.byref(params), img.ctypes.data_as(_u8p), C.byref(rays), C.byref(secs)))
+        return int(rays.value), float(secs.value)
 
     def info(self):
         n, v, li = C.c_int32(), C.c_int32(), LaunchInfo()
@@ -333,6 +403,10 @@ class MultiRenderer:
 
 def shard_block_bytes(params):
     return int(lib().r1_shard_block_bytes(C.byref(params)))
+
+
+def shard_record_bytes(params):
+    return int(lib().r1_shard_record_bytes(C.byref(params)))
 
 
 def tile_count(params):

@@ -188,14 +188,14 @@ struct Builder
         // (the balls sat four levels deep and made the boxes above them 2.7 high instead of 0.5).  Up to `leaf_max`
         // spheres more than R1_BVH_PEEL_RATIO (4) x the node's median radius become ONE leaf here and the rest keeps tight
         // boxes: large scene 24.3 -> 26.5 Grays/s, 100 004-sphere scene 12.2 -> 12.8 (tools: R1_BVH_PEEL=0 switches it off).
-        static const int peel_env = getenv("R1_BVH_PEEL") ? atoi(getenv("R1_BVH_PEEL")) : 1;
+        static const int peel_env = (int)r1_knob("R1_BVH_PEEL", 1);
         if (peel_env && !force_median && depth + need + 2 < R1_BVH_STACK && n > 2u * (uint32_t)leaf_max) // (a peel costs a level)
         {
             std::vector<double> rs(n);
             for (uint32_t i = 0; i < n; ++i)
                 rs[i] = sphere[order[b + i]].rmax;
             std::nth_element(rs.begin(), rs.begin() + n / 2, rs.end());
-            static const double ratio_env = getenv("R1_BVH_PEEL_RATIO") ? atof(getenv("R1_BVH_PEEL_RATIO")) : 4.0;
+            static const double ratio_env = r1_knob_f("R1_BVH_PEEL_RATIO", 4.0);
             const double big = ratio_env * rs[n / 2];
             uint32_t nb = 0;
             for (uint32_t i = b; i < e; ++i)
@@ -415,7 +415,7 @@ void r1_build_bvh(uint32_t na, const float *cx, const float *cy, const float *cz
             const double w2_med = 80.0 * ldexp(1.0, -24) / (2.0 * r_med) + ldexp(1.0, -19);
             local = 4.0 * w2_med * G2 > 0.25 * r_med;
         }
-        static const int pad_env = getenv("R1_BVH_PAD_LOCAL") ? atoi(getenv("R1_BVH_PAD_LOCAL")) : -1; // tuning experiments
+        static const int pad_env = (int)r1_knob("R1_BVH_PAD_LOCAL", -1); // tuning experiments
         if (pad_env >= 0)
             local = pad_env != 0;
         B.pad_local = local;
@@ -469,7 +469,7 @@ void r1_build_bvh(uint32_t na, const float *cx, const float *cy, const float *cz
     // as build() allocates them).  Child references are rewritten; node 0 stays the root.
     {
         const uint32_t nn = (uint32_t)(out.nodes.size() / 16);
-        static const int top_env = getenv("R1_BVH_TOP") ? atoi(getenv("R1_BVH_TOP")) : R1_BVH_TOP_NODES; // tuning experiments
+        static const int top_env = (int)r1_knob("R1_BVH_TOP", R1_BVH_TOP_NODES); // tuning experiments
         const uint32_t top = (uint32_t)std::max(0, top_env);
         if (nn > 1 && top > 1)
         {

@@ -26,7 +26,8 @@ extern "C" int r1_trace_mode(int variant, int big, int wanted); // 0 samples + o
 extern "C" hipError_t r1_launch_resolve(const R1ResolveArgs *args, hipStream_t stream);
 extern "C" hipError_t r1_launch_wavefront(R1WaveArgs *w, int blocks, hipStream_t stream);
 extern "C" hipError_t r1_launch_assemble(const void *blocks, void *rgb, int width, int height, int tile_w, int tile_h, int tiles_x,
-                                         int tiles_total, int num_shards, int tiles_per_shard, size_t shard_stride, hipStream_t stream);
+                                         int tiles_total, int num_shards, int tiles_per_shard, size_t shard_stride, void *total_rays,
+                                         hipStream_t stream);
 extern "C" hipError_t r1_trace_occupancy(int variant, int big, int mode, size_t dyn_lds, int *blocks_per_cu);
 extern "C" int r1_params_check(const r1_params *p); // r1_host.cpp
 
@@ -302,7 +303,7 @@ static std::vector<R1Group> build_groups(uint32_t na, const std::vector<double> 
     // Grouping trades level-1 tests for extra member slots in the exact phase: it pays once the
     // sweep is long (large scene: 484 spheres, 1.5x), not for a few dozen spheres (medium scene:
     // 46 spheres, 27.2 vs 24.5 Grays/s ungrouped vs grouped) — R1_GROUP_MAX overrides for tuning.
-    static const long gmax_env = getenv("R1_GROUP_MAX") ? atol(getenv("R1_GROUP_MAX")) : 0; // 0: automatic
+    static const long gmax_env = (long)r1_knob("R1_GROUP_MAX", 0); // 0: automatic
     const long gmax_want = gmax_env > 0 ? gmax_env : (na > R1_GROUP_MIN_SPHERES ? R1_GROUP_MAX : 1);
     const int gmax = gmax_want > R1_GROUP_MAX ? R1_GROUP_MAX : (int)gmax_want;
     std::vector<R1Group> groups;
@@ -361,7 +362,7 @@ static std::vector<R1Group> build_groups(uint32_t na, const std::vector<double> 
             double rmin = 1e300;
             for (uint32_t a : tryg)
                 rmin = fmin(rmin, r[a]);
-            static const double ratio = getenv("R1_GROUP_RATIO") ? atof(getenv("R1_GROUP_RATIO")) : R1_GROUP_RATIO;
+            static const double ratio = r1_knob_f("R1_GROUP_RATIO", R1_GROUP_RATIO);
             ok = g.radius <= (ratio < R1_GROUP_RATIO ? ratio : R1_GROUP_RATIO) * rmin; // the slack analysis needs <= R1_GROUP_RATIO
         }
         if (ok)
@@ -497,7 +498,7 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
         std::vector<float> fx(na ? na : 1), fy(na ? na : 1), fz(na ? na : 1), fr(na ? na : 1);
         for (uint32_t a = 0; a < na; ++a)
             fx[a] = exact[4 * a + 0], fy[a] = exact[4 * a + 1], fz[a] = exact[4 * a + 2], fr[a] = exact[4 * a + 3];
-        static const int leaf_env = getenv("R1_BVH_LEAF") ? atoi(getenv("R1_BVH_LEAF")) : 0;
+        static const int leaf_env = (int)r1_knob("R1_BVH_LEAF", 0);
         // leaf size: 4 spheres (2 pairs) on the reference's scenes; 8 on big lattices (measured:
         // 100 004 spheres 3.43 ms against 3.67 ms per 1920x1080x4 frame)
         const int leaf_default = na > R1_MAX_ACTIVE_10BIT ? 2 * R1_BVH_LEAF : R1_BVH_LEAF;
@@ -517,15 +518,20 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
         (rc = ensure(c->shade, shade.size() * 4)) || (rc = ensure(c->mat, mat.size() * 4)) ||
         (rc = ensure(c->members, members.size() * 4)))
         return rc;
+    // Uploads go through the context's OWN stream (then one wait): librays1 never touches the null stream.  A process
+    // that keeps K frames in flight on K contexts with GPU_MAX_HW_QUEUES = K would otherwise hand one of its K hardware
+    // queues to the null stream, and two frames would share a queue and run one after the other (measured: 20 frames
+    // land in 20.1 ms instead of 17.0, tools/submit_times.py, profiles/r03/stream_queue_mapping.txt).
     R1_HIP(hipStreamSynchronize(c->stream));
-    R1_HIP(hipMemcpy(c->sweep.p, sweep.data(), sweep.size() * 4, hipMemcpyHostToDevice));
-    R1_HIP(hipMemcpy(c->exact.p, exact.data(), exact.size() * 4, hipMemcpyHostToDevice));
-    R1_HIP(hipMemcpy(c->shade.p, shade.data(), shade.size() * 4, hipMemcpyHostToDevice));
-    R1_HIP(hipMemcpy(c->mat.p, mat.data(), mat.size() * 4, hipMemcpyHostToDevice));
-    R1_HIP(hipMemcpy(c->members.p, members.data(), members.size() * 4, hipMemcpyHostToDevice));
-    R1_HIP(hipMemcpy(c->bvh_nodes.p, bvh.nodes.data(), bvh.nodes.size() * 4, hipMemcpyHostToDevice));
-    R1_HIP(hipMemcpy(c->bvh_prims.p, bvh.prims.data(), bvh.prims.size() * 4, hipMemcpyHostToDevice));
-    R1_HIP(hipMemcpy(c->bvh_ids.p, bvh.ids.data(), bvh.ids.size() * 4, hipMemcpyHostToDevice));
+    R1_HIP(hipMemcpyAsync(c->sweep.p, sweep.data(), sweep.size() * 4, hipMemcpyHostToDevice, c->stream));
+    R1_HIP(hipMemcpyAsync(c->exact.p, exact.data(), exact.size() * 4, hipMemcpyHostToDevice, c->stream));
+    R1_HIP(hipMemcpyAsync(c->shade.p, shade.data(), shade.size() * 4, hipMemcpyHostToDevice, c->stream));
+    R1_HIP(hipMemcpyAsync(c->mat.p, mat.data(), mat.size() * 4, hipMemcpyHostToDevice, c->stream));
+    R1_HIP(hipMemcpyAsync(c->members.p, members.data(), members.size() * 4, hipMemcpyHostToDevice, c->stream));
+    R1_HIP(hipMemcpyAsync(c->bvh_nodes.p, bvh.nodes.data(), bvh.nodes.size() * 4, hipMemcpyHostToDevice, c->stream));
+    R1_HIP(hipMemcpyAsync(c->bvh_prims.p, bvh.prims.data(), bvh.prims.size() * 4, hipMemcpyHostToDevice, c->stream));
+    R1_HIP(hipMemcpyAsync(c->bvh_ids.p, bvh.ids.data(), bvh.ids.size() * 4, hipMemcpyHostToDevice, c->stream));
+    R1_HIP(hipStreamSynchronize(c->stream)); // the host vectors go out of scope
     c->n_bvh_nodes = (uint32_t)(bvh.nodes.size() / 16);
     c->n_bvh_leaves = bvh.n_leaves;
     c->bvh_depth = bvh.max_depth;
@@ -641,7 +647,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     // for the throughput entry point (a lane owns a pixel: no sample records, no resolve launch, ~10 % slower)
     // big-scene kernels: > 1023 hittable spheres (10-bit hit indices), or — tree kernels — a node table too large for LDS
     const int big_scene_ = (c->n_active > R1_MAX_ACTIVE_10BIT || ((variant == 4 || variant == 5) && c->n_bvh_nodes > R1_NODES_LDS_MAX)) ? 1 : 0;
-    static const int tp_mode_env = getenv("R1_TP_MODE") ? atoi(getenv("R1_TP_MODE")) : -1; // tuning experiments
+    static const int tp_mode_env = (int)r1_knob("R1_TP_MODE", -1); // tuning experiments
     const int tp_mode = c->pixel_mode ? 2 : (tp_mode_env >= 0 && tp_mode_env <= 2 ? tp_mode_env : 0);
     const int mode = variant == 6 ? 0 : r1_trace_mode(variant, big_scene_, throughput_mode ? tp_mode : 1);
     const bool pixel_mode = mode == 2;
@@ -682,7 +688,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     a.queue = (uint32_t *)((char *)c->counters.p + 1024);
     a.nq = 1;
     {
-        static const int coop_env = getenv("R1_COOP_LANES") ? atoi(getenv("R1_COOP_LANES")) : -1;
+        static const int coop_env = (int)r1_knob("R1_COOP_LANES", -1);
         a.coop_lanes = coop_env >= 0 ? (uint32_t)coop_env : R1_COOP_LANES;
     }
     a.samples = (float4 *)c->samples.p;
@@ -701,7 +707,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     const int big = big_scene_;
     a.bvh_depth = c->bvh_depth > 0 ? c->bvh_depth : 1;
     // the workgroups' LDS copy of the node table: all of it for small scenes, the breadth-first top for big ones
-    static const int big_top_env = getenv("R1_BIG_TOP") ? atoi(getenv("R1_BIG_TOP")) : R1_BVH_TOP_NODES; // tuning experiments
+    static const int big_top_env = (int)r1_knob("R1_BIG_TOP", R1_BVH_TOP_NODES); // tuning experiments
     a.bvh_lds_f4 = !(variant == 4 || variant == 5) ? 0u : (!big ? 4u * c->n_bvh_nodes : 4u * std::min<uint32_t>(c->n_bvh_nodes, (uint32_t)std::max(0, big_top_env)));
     const int occ_slot = variant + 8 * big + 16 * mode;
     if (c->occupancy[occ_slot] == 0)
@@ -713,7 +719,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
         per_cu = 1;
     if (per_cu > 8)
         per_cu = 8;
-    static const int per_cu_env = getenv("R1_BLOCKS_PER_CU") ? atoi(getenv("R1_BLOCKS_PER_CU")) : 0; // tuning experiments
+    static const int per_cu_env = (int)r1_knob("R1_BLOCKS_PER_CU", 0); // tuning experiments
     if (per_cu_env > 0 && per_cu_env < per_cu)
         per_cu = per_cu_env;
     // Persistent grid.  Latency mode (the synchronous host entry points: one frame, the caller
@@ -723,8 +729,8 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     // a wave needs many times that much work to stay full — give every lane
     // >= R1_SAMPLES_PER_LANE samples and let the other frames fill the CUs a small frame leaves.
     long long blocks = (long long)c->cus * per_cu;
-    static const long long spl_env = getenv("R1_SAMPLES_PER_LANE") ? atoll(getenv("R1_SAMPLES_PER_LANE")) : R1_SAMPLES_PER_LANE;
-    static const long long minb_env = getenv("R1_MIN_BLOCKS") ? atoll(getenv("R1_MIN_BLOCKS")) : R1_MIN_BLOCKS;
+    static const long long spl_env = r1_knob("R1_SAMPLES_PER_LANE", R1_SAMPLES_PER_LANE);
+    static const long long minb_env = r1_knob("R1_MIN_BLOCKS", R1_MIN_BLOCKS);
     long long needed = ((long long)c->total_samples + R1_BLOCK - 1) / R1_BLOCK;
     if (throughput_mode)
     {
@@ -745,7 +751,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     // and save atomics — measured at N = 1: 256 -> 1.227 ms, 1024 -> 1.197, 4096 -> 1.231 —
     // but they must stay small against a wave's share of the frame (8 shards: 1024 costs 12 %).
     {
-        static const int chunk_max_env = getenv("R1_CHUNK") ? atoi(getenv("R1_CHUNK")) : 0, chunk_min_env = getenv("R1_CHUNK_MIN") ? atoi(getenv("R1_CHUNK_MIN")) : 0;
+        static const int chunk_max_env = (int)r1_knob("R1_CHUNK", 0), chunk_min_env = (int)r1_knob("R1_CHUNK_MIN", 0);
         const long long waves = blocks * (R1_BLOCK / 64);
         long long cm = (long long)c->total_samples / (waves * 12);
         cm = cm < R1_CHUNK ? R1_CHUNK : (cm > R1_CHUNK_BIG ? R1_CHUNK_BIG : cm);
@@ -775,7 +781,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     }
     if (mode == 1)
     {
-        static const int nq_env = getenv("R1_NQ") ? atoi(getenv("R1_NQ")) : 0, ch_env = getenv("R1_CHUNK") ? atoi(getenv("R1_CHUNK")) : 0;
+        static const int nq_env = (int)r1_knob("R1_NQ", 0), ch_env = (int)r1_knob("R1_CHUNK", 0);
         long long nq = nq_env > 0 ? nq_env : R1_SUBQUEUES;
         // a wave only ever pulls from its home sub-queue (r1_kernels.hip: home = (4 (block / 8) + wave) % nq), so every
         // sub-queue needs home waves: the full groups of 8 workgroups must cover all nq residues
@@ -959,7 +965,8 @@ static int render_host(r1_context *c, const r1_params *p, uint8_t *rgb_out, uint
         // device order is [padded tile][sample][pixel in tile]; the ABI order is
         // ((y*width + x)*spp + s)
         std::vector<float> tmp((size_t)c->total_samples * 4);
-        R1_HIP(hipMemcpy(tmp.data(), c->samples.p, tmp.size() * 4, hipMemcpyDeviceToHost));
+        R1_HIP(hipMemcpyAsync(tmp.data(), c->samples.p, tmp.size() * 4, hipMemcpyDeviceToHost, c->stream));
+        R1_HIP(hipStreamSynchronize(c->stream));
         const int tiles_x = (p->width + p->tile_w - 1) / p->tile_w;
         for (uint32_t lt = 0; lt < c->n_local_tiles; ++lt)
         {
@@ -993,11 +1000,72 @@ extern "C" int r1_render_samples(r1_context *c, const r1_params *p, uint8_t *rgb
     return render_host(c, p, rgb_out, num_rays_out, nullptr, samples_out);
 }
 
+// Pipelined form of r1_render (frames in flight, results on the HOST): the frame is enqueued with the throughput
+// kernels on `hip_stream` (or the context's stream), followed by the copies of the row-major image and of the ray
+// count into the caller's buffers.  Nothing is waited for: the buffers are valid once the stream is idle (r1_sync for
+// the context's stream).  One frame per context at a time — a caller keeps K frames in flight with K contexts, as
+// bench.py does.  Page-locked buffers (r1_host_alloc) let the copies overlap the other frames' kernels; pageable
+// memory works but makes each copy wait for its frame.
+extern "C" int r1_render_async(r1_context *c, const r1_params *p, uint8_t *rgb_out, uint64_t *num_rays_out, void *hip_stream)
+{
+    if (!c || !p || ((rgb_out == nullptr) != (num_rays_out == nullptr)))
+    {
+        r1_set_error("r1_render_async: null argument (rgb_out and num_rays_out are given together, or both NULL)");
+        return R1_EINVAL;
+    }
+    int rc = r1_params_check(p);
+    if (rc)
+        return rc;
+    if (p->num_shards != 1)
+    {
+        r1_set_error("r1_render_async renders whole frames (num_shards == 1); shards go through r1_render_shard_device");
+        return R1_EINVAL;
+    }
+    R1_HIP(hipSetDevice(c->device));
+    const size_t img_bytes = (size_t)p->width * p->height * 3;
+    if ((rc = ensure(c->image, img_bytes + 64)))
+        return rc;
+    if ((rc = ensure(c->counters, R1_COUNTER_BYTES + 64)))
+        return rc;
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    void *d_rays = (char *)c->counters.p + R1_COUNTER_BYTES;
+    if ((rc = enqueue_frame(c, p, c->image.p, 0, d_rays, st, true)))
+        return rc;
+    if (rgb_out) // (both NULL: the frame stays in the context's device buffers — a measurement aid, bench.py's value_device_resident)
+    {
+        R1_HIP(hipMemcpyAsync(rgb_out, c->image.p, img_bytes, hipMemcpyDeviceToHost, st));
+        R1_HIP(hipMemcpyAsync(num_rays_out, d_rays, 8, hipMemcpyDeviceToHost, st));
+    }
+    return R1_OK;
+}
+
+extern "C" int r1_host_alloc(size_t bytes, void **out)
+{
+    if (!out || bytes == 0)
+        return R1_EINVAL;
+    *out = nullptr;
+    if (r1_device_count() <= 0)
+        return R1_ENODEVICE;
+    R1_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return R1_OK;
+}
+
+extern "C" void r1_host_free(void *p)
+{
+    if (p)
+        (void)hipHostFree(p);
+}
+
 extern "C" int r1_render_shard_device(r1_context *c, const r1_params *p, void *d_block, void *d_num_rays, void *hip_stream)
 {
     if (!c || !p || !d_block || !d_num_rays)
     {
         r1_set_error("r1_render_shard_device: null argument");
+        return R1_EINVAL;
+    }
+    if ((uintptr_t)d_num_rays & 7u)
+    {
+        r1_set_error("r1_render_shard_device: d_num_rays must be 8-byte aligned (a uint64 the kernels store and add to atomically)");
         return R1_EINVAL;
     }
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
@@ -1011,12 +1079,17 @@ extern "C" int r1_render_shard_device_once(r1_context *c, const r1_params *p, vo
         r1_set_error("r1_render_shard_device_once: null argument");
         return R1_EINVAL;
     }
+    if ((uintptr_t)d_num_rays & 7u)
+    {
+        r1_set_error("r1_render_shard_device_once: d_num_rays must be 8-byte aligned");
+        return R1_EINVAL;
+    }
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     return enqueue_frame(c, p, d_block, 1, d_num_rays, st, false);
 }
 
-extern "C" int r1_assemble_device_strided(r1_context *c, const r1_params *p, const void *d_blocks, size_t shard_stride_bytes, void *d_rgb,
-                                          void *hip_stream)
+static int assemble_common(r1_context *c, const r1_params *p, const void *d_blocks, size_t shard_stride_bytes, void *d_rgb, void *d_total_rays,
+                           void *hip_stream)
 {
     if (!c || !p || !d_blocks || !d_rgb)
     {
@@ -1035,12 +1108,33 @@ extern "C" int r1_assemble_device_strided(r1_context *c, const r1_params *p, con
         r1_set_error("r1_assemble_device: shard stride %zu smaller than a shard block (%zu bytes)", shard_stride_bytes, tight);
         return R1_EINVAL;
     }
+    if (d_total_rays && (((uintptr_t)d_total_rays | (uintptr_t)d_blocks | shard_stride_bytes) & 7u))
+    {
+        r1_set_error("r1_assemble_device_records: records and the total must be 8-byte aligned");
+        return R1_EINVAL;
+    }
     R1_HIP(hipSetDevice(c->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     const int tiles_x = (p->width + p->tile_w - 1) / p->tile_w;
     R1_HIP(r1_launch_assemble(d_blocks, d_rgb, p->width, p->height, p->tile_w, p->tile_h, tiles_x, total, p->num_shards, per,
-                              shard_stride_bytes, st));
+                              shard_stride_bytes, d_total_rays, st));
     return R1_OK;
+}
+
+extern "C" int r1_assemble_device_strided(r1_context *c, const r1_params *p, const void *d_blocks, size_t shard_stride_bytes, void *d_rgb,
+                                          void *hip_stream)
+{
+    return assemble_common(c, p, d_blocks, shard_stride_bytes, d_rgb, nullptr, hip_stream);
+}
+
+extern "C" int r1_assemble_device_records(r1_context *c, const r1_params *p, const void *d_records, void *d_rgb, void *d_total_rays, void *hip_stream)
+{
+    if (!d_total_rays)
+    {
+        r1_set_error("r1_assemble_device_records: null d_total_rays");
+        return R1_EINVAL;
+    }
+    return assemble_common(c, p, d_records, r1_shard_record_bytes(p), d_rgb, d_total_rays, hip_stream);
 }
 
 extern "C" int r1_assemble_device(r1_context *c, const r1_params *p, const void *d_blocks, void *d_rgb, void *hip_stream)
@@ -1089,7 +1183,8 @@ extern "C" int r1_last_stats(r1_context *c, uint64_t *out16)
         return R1_EINVAL;
     R1_HIP(hipSetDevice(c->device));
     R1_HIP(hipStreamSynchronize(c->stream));
-    R1_HIP(hipMemcpy(out16, (char *)c->counters.p + 128, 128, hipMemcpyDeviceToHost));
+    R1_HIP(hipMemcpyAsync(out16, (char *)c->counters.p + 128, 128, hipMemcpyDeviceToHost, c->stream));
+    R1_HIP(hipStreamSynchronize(c->stream));
     return R1_OK;
 }
 
@@ -1104,7 +1199,8 @@ extern "C" int r1_last_wave_log(r1_context *c, uint64_t *out, size_t cap_waves, 
         return R1_EINVAL;
     R1_HIP(hipSetDevice(c->device));
     R1_HIP(hipStreamSynchronize(c->stream));
-    R1_HIP(hipMemcpy(out, c->wave_log.p, (size_t)c->wave_log_waves * 32, hipMemcpyDeviceToHost));
+    R1_HIP(hipMemcpyAsync(out, c->wave_log.p, (size_t)c->wave_log_waves * 32, hipMemcpyDeviceToHost, c->stream));
+    R1_HIP(hipStreamSynchronize(c->stream));
     return R1_OK;
 }
 

@@ -44,6 +44,27 @@
                                // the allocation carries 64 more bytes: the published ray count of the synchronous entry points
 #define R1_COOP_LANES 2        // R1TraceArgs::coop_lanes (one synchronous frame: 2 -> 1.144 ms, 4 -> 1.160, 8 -> 1.193, 16 -> 1.263)
 
+// Tuning knobs.  The SHIPPED library never reads the environment: what it does depends on its arguments only.  A build made
+// with -DR1_TUNING (`make tuning` -> lib/librays1_tuning.so; the scripts under tools/ load it explicitly) reads the R1_*
+// variables named at the call sites, once per process — launch shapes and conservative index layouts that produce the
+// same pixels and ray counts; the defaults are what every number in DESIGN.md refers to.
+#ifdef R1_TUNING
+#include <stdlib.h>
+static inline long long r1_knob(const char *name, long long dflt)
+{
+    const char *v = getenv(name);
+    return v ? atoll(v) : dflt;
+}
+static inline double r1_knob_f(const char *name, double dflt)
+{
+    const char *v = getenv(name);
+    return v ? atof(v) : dflt;
+}
+#else
+static inline long long r1_knob(const char *, long long dflt) { return dflt; }
+static inline double r1_knob_f(const char *, double dflt) { return dflt; }
+#endif
+
 // Division of n < 2^31 by a launch constant: pow2 ? n >> shift : mulhi(n, mul) >> shift, with
 // mul = ceil(2^(32+shift) / d), shift = floor(log2 d) (exact for every n < 2^31; r1_capi.cpp).
 struct R1FastDiv

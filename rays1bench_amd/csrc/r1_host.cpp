@@ -303,6 +303,14 @@ extern "C" size_t r1_shard_block_bytes(const r1_params *p)
     return (size_t)per * p->tile_w * p->tile_h * 3;
 }
 
+// One shard's gather record: the dense tile block, padded to a multiple of 8 bytes, then the shard's uint64 ray
+// count (8-byte aligned for any tile size: the kernels store it as one 64-bit word).
+extern "C" size_t r1_shard_record_bytes(const r1_params *p)
+{
+    const size_t block = r1_shard_block_bytes(p);
+    return block ? ((block + 7u) & ~(size_t)7u) + 8u : 0u;
+}
+
 // ---- output formats (src/common/common.h) ---------------------------------------------
 
 extern "C" int r1_tga_write_rgb24(const char *filename, int32_t width, int32_t height, uint8_t *pixels)

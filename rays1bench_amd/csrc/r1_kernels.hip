@@ -593,7 +593,8 @@ __device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const bo
 #define R1_BVH_DONE 0xFFFFFFFFu
 
 // STATS (diagnostic build): wstat[2] wave trips of the node loop, [3] wave trips of the leaf
-// pair loop, [9] node visits summed over lanes, [5] sphere-pair tests summed over lanes.
+// pair loop, [9] node visits summed over lanes, [5] sphere-pair tests summed over lanes, [16] leaf trips
+// summed over lanes (published in stats slot 14).
 // One child box {m, e} against the ray, inflated by the node's pad (pa = pad * |1/d| per axis, computed once
 // per node visit for both children; pad = A |o - C|^2 + K, conservative with respect to the reference's fp32
 // sphere test AND to this test's own rounding: r1_bvh.cpp).  Slab form a = m / d - o / d (one fused
@@ -689,13 +690,12 @@ __device__ __forceinline__ void trav_start(Trav &t)
 // to the fresh rays of the lanes that have been shaded and refilled meanwhile.  The longest of 64
 // walks no longer sets the trip count of the loops for everybody (a wave made 14.3 node trips for a mean
 // of 7.0 visits per lane), at the price of shading ~3/4 of the wave at a time.  Called by all 64 lanes.
-// MAJORITY = false: while-while (all lanes on inner nodes descend until each has reached a leaf or finished, then
-// the leaves are tested).  MAJORITY = true: ONE step per trip, of the kind most walking lanes are waiting for.
-// Measured on the large scene (tools/bvh_stats.py): lane utilisation of the node / leaf steps 0.48 / 0.58 ->
-// 0.70 / 0.65, a third fewer trips — and +1.5 % frames in flight, -2 % for one synchronous frame, because the vote costs
-// ~20 VALU instructions per trip in a kernel that is bound by its VALU instruction count.
+// The walk is while-while: all lanes on inner nodes descend until each has reached a leaf or finished, then the leaves
+// are tested.  (Round 2 also carried a voting form — one step per trip, of the kind most walking lanes wait for: lane
+// utilisation of the node / leaf steps 0.53 / 0.69 -> 0.74 / 0.75, and 5 % SLOWER once the node table sat in LDS, because
+// the vote costs ~20 VALU instructions per trip; removed in round 3)
 // LN: the node table is read from `lnodes`, the workgroup's copy in LDS (the trace kernel on small scenes), instead of S.bvh_nodes.
-template <bool STATS, bool CARRY, bool MAJORITY, bool LN>
+template <bool STATS, bool CARRY, bool LN>
 __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, const V3 d, Trav &tv, uint32_t *trav, const int tid,
                                             const uint32_t n_alive, unsigned long long *wstat, const float4 *lnodes /* LDS */, const uint32_t top = 0u /* !LN: nodes [0, top) are in lnodes */)
 {
@@ -720,80 +720,6 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
             break;
         if (CARRY && R1_CARRY_DIV * (uint32_t)__popcll(walking) <= n_alive)
             break; // (n_alive <= 3: never true while a lane walks, so the last walks of a wave run to their end)
-        if (MAJORITY)
-        {
-        // one step per trip, of the kind most lanes are waiting for: a node visit for the lanes on inner nodes, or
-        // ONE sphere-pair test for the lanes on leaves (a leaf reference counts its pairs down as they are tested)
-        const unsigned long long on_leaf = __ballot(cur != R1_BVH_DONE && (cur & 0x80000000u));
-        if (2u * (uint32_t)__popcll(on_leaf) <= (uint32_t)__popcll(walking))
-        {
-            if (!(cur & 0x80000000u))
-            {
-                if (STATS)
-                {
-                    wstat[9] += 1;
-                    if ((tid & 63) == __ffsll((long long)__ballot(1)) - 1)
-                        wstat[2] += 1;
-                }
-                float4 q0, q1, q2, q3;
-                if (LN || cur < top) // (big scenes: the top of the tree, breadth first, is in LDS too; per lane)
-                {
-                    q0 = lnodes[4 * cur + 0], q1 = lnodes[4 * cur + 1], q2 = lnodes[4 * cur + 2], q3 = lnodes[4 * cur + 3];
-                    if (!LN) // keeps the two loads apart: merged, they become one load through a generic pointer (flat_load_dword x 16)
-                        asm volatile("" : "+v"(q0.x), "+v"(q1.x), "+v"(q2.x), "+v"(q3.x));
-                }
-                else
-                    q0 = nodes[4 * (size_t)cur + 0], q1 = nodes[4 * (size_t)cur + 1], q2 = nodes[4 * (size_t)cur + 2],
-                    q3 = nodes[4 * (size_t)cur + 3];
-                float tn0, tn1;
-                float dist2 = r2;
-                if (S.bvh_pad_local) // wave-uniform: scenes of small spheres measure the pad's distance per node, |m0 + m1 - 2 o|^2
-                {
-                    const float sx = __fmaf_rn(-2.0f, o.x, q0.x + q0.y), sy = __fmaf_rn(-2.0f, o.y, q0.z + q0.w), sz = __fmaf_rn(-2.0f, o.z, q1.x + q1.y);
-                    dist2 = __fmaf_rn(sz, sz, __fmaf_rn(sy, sy, sx * sx));
-                }
-                const float pad = __fmaf_rn(q3.x, dist2, q3.y);
-                const V3 pa = mk(pad * ainv.x, pad * ainv.y, pad * ainv.z);
-                const bool h0 = bvh_box(q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, pa, oi, inv, ainv, best, tn0);
-                const bool h1 = bvh_box(q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, pa, oi, inv, ainv, best, tn1);
-                const uint32_t c0 = __float_as_uint(q3.z), c1 = __float_as_uint(q3.w);
-                if (h0 && h1)
-                {
-                    const bool swap = tn1 < tn0;
-                    trav[sp * R1_BLOCK + tid] = swap ? c0 : c1;
-                    ++sp;
-                    cur = swap ? c1 : c0;
-                }
-                else if (h0)
-                    cur = c0;
-                else if (h1)
-                    cur = c1;
-                else if (sp > 0)
-                    cur = trav[--sp * R1_BLOCK + tid];
-                else
-                    cur = R1_BVH_DONE;
-                // an empty leaf (count 0) is complete at once
-                if ((cur & 0xF0000000u) == 0x80000000u)
-                    cur = sp > 0 ? trav[--sp * R1_BLOCK + tid] : R1_BVH_DONE;
-            }
-        }
-        else if (cur != R1_BVH_DONE && (cur & 0x80000000u))
-        {
-            if (STATS)
-            {
-                wstat[5] += (((cur >> 28) & 7u) < 2u ? 1ull : 2ull) | (1ull << 32); // sphere pairs | leaf trips of this lane << 32
-                if ((tid & 63) == __ffsll((long long)__ballot(1)) - 1)
-                    wstat[3] += 1;
-            }
-            const uint32_t first = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
-            const uint32_t take = cnt < 2u ? cnt : 2u; // up to four spheres per trip
-            leaf_quad(prims, ids, first, take, o, d, best, best_id);
-            cur = cur + take - (take << 28); // next pairs, `take` fewer to go
-            if ((cur & 0x70000000u) == 0u)
-                cur = sp > 0 ? trav[--sp * R1_BLOCK + tid] : R1_BVH_DONE;
-        }
-        continue;
-        }
         // inner nodes: descend to the nearer child, remember the farther one
         while (!(cur & 0x80000000u))
         {
@@ -852,7 +778,8 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
                 const uint32_t take = cnt - j < 2u ? 1u : 2u;
                 if (STATS)
                 {
-                    wstat[5] += (unsigned long long)take | (1ull << 32);
+                    wstat[5] += (unsigned long long)take; // sphere pairs tested by this lane
+                    wstat[16] += 1ull;                    // leaf trips of this lane
                     if ((tid & 63) == __ffsll((long long)__ballot(1)) - 1)
                         wstat[3] += 1;
                 }
@@ -873,7 +800,7 @@ __device__ __forceinline__ void sweep_bvh(const R1DeviceScene &S, const bool ali
     trav_start(tv);
     if (!alive)
         tv.cur = R1_BVH_DONE;
-    bvh_advance<STATS, false, false, false>(S, o, d, tv, trav, tid, 64u, wstat, nullptr);
+    bvh_advance<STATS, false, false>(S, o, d, tv, trav, tid, 64u, wstat, nullptr);
     if (tv.best_id != 0xFFFFFFFFu)
     {
         t_max = tv.best;
@@ -1258,10 +1185,10 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
 {
     constexpr bool LAT = MODE == 1, PIX = MODE == 2;
     typedef typename IdxType<BIG>::type IDX;
-    unsigned long long wstat[16];
+    unsigned long long wstat[17];
     if (STATS)
     {
-        for (int i = 0; i < 16; ++i)
+        for (int i = 0; i < 17; ++i)
             wstat[i] = 0;
         wstat[14] = __builtin_readcyclecounter();
     }
@@ -1322,15 +1249,6 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
     // run every second iteration at ~60 % of the lanes.  29.4 -> 30.5 Grays/s (thresholds 20 / 32 / 44 / never by count:
     // 30.2 / 30.5 / 30.6 / 30.4).  Not for a synchronous frame: what the lanes hold when the queue runs dry is the
     // frame's tail (1.17 -> 1.23 ms with spares).
-// One step per trip by majority vote (bvh_advance<..., MAJORITY = true>) was +1.5 % for frames in flight while a node visit
-// was four global loads; with the node table in LDS the vote's ~20 instructions per trip cost more than the fuller trips
-// bring: while-while + carry-over 32.0 against 30.5 Grays/s (and 1.16 against 1.27 ms for a synchronous frame).  The
-// big-scene kernels, whose node table stays behind the vector L1, still preferred the vote at seven waves per SIMD (100 004
-// spheres: 13.1 against 12.5) and no longer do at eight (14.6 against 14.85): every product kernel walks while-while now,
-// the voting walk stays in the source as an option of the build.
-#ifndef R1_TP_MAJORITY
-#define R1_TP_MAJORITY 0
-#endif
 #ifndef R1_SPARE
 #define R1_SPARE 1
 #endif
@@ -1497,8 +1415,8 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
         }
         else if (VARIANT == 4)
         {
-            // while-while with carry-over (the voting walk, MAJORITY = true, is an option of the build: R1_TP_MAJORITY)
-            bvh_advance<STATS, true, (R1_TP_MAJORITY && (STATS || !LAT)), LN>(A.scene, p.o, p.d, tv, s_trav, tid, (uint32_t)__popcll(live_now), wstat, lnodes, top);
+            // while-while with carry-over
+            bvh_advance<STATS, true, LN>(A.scene, p.o, p.d, tv, s_trav, tid, (uint32_t)__popcll(live_now), wstat, lnodes, top);
             ready = alive && tv.cur == R1_BVH_DONE;
             if (tv.best_id != 0xFFFFFFFFu)
                 t_hit = tv.best, hit = (int)tv.best_id;
@@ -1546,8 +1464,8 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
         if (VARIANT == 4)
         {
             // per-lane counters of sweep_bvh
-            const int slots[3] = {2, 3, 5};
-            for (int q = 0; q < 3; ++q)
+            const int slots[4] = {2, 3, 5, 16};
+            for (int q = 0; q < 4; ++q)
             {
                 unsigned long long c = wstat[slots[q]];
                 for (int off = 32; off > 0; off >>= 1)
@@ -1568,6 +1486,8 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
             atomicMax(&A.stats[11], ~wstat[8]);                     // ~shortest wave
             atomicMax(&A.stats[12], (unsigned long long)__builtin_readcyclecounter());  // last wave end (this XCD's counter)
             atomicMax(&A.stats[13], ~wstat[14]);                    // ~first wave start
+            if (VARIANT == 4)
+                atomicAdd(&A.stats[14], wstat[16]);                 // tree: leaf trips summed over lanes
         }
     }
 
@@ -1742,8 +1662,17 @@ __global__ void __launch_bounds__(256) r1_resolve_kernel(const R1ResolveArgs A)
 // Scatter gathered dense tile blocks (shard-major) into a row-major image.
 __global__ void __launch_bounds__(256)
     r1_assemble_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ rgb, int width, int height, int tile_w, int tile_h,
-                       int tiles_x, int tiles_total, int num_shards, int tiles_per_shard, size_t shard_stride)
+                       int tiles_x, int tiles_total, int num_shards, int tiles_per_shard, size_t shard_stride, unsigned long long *total_rays)
 {
+    // gathered RECORDS (block + uint64 count at the end of every stride): the frame's ray count is the sum of the
+    // shards' counts (rayweek1.cpp:809-813), written next to the image so that one copy brings both to the host
+    if (total_rays && blockIdx.x == 0 && threadIdx.x == 0)
+    {
+        unsigned long long sum = 0;
+        for (int sh = 0; sh < num_shards; ++sh)
+            sum += *(const unsigned long long *)(blocks + (size_t)(sh + 1) * shard_stride - 8);
+        *total_rays = sum;
+    }
     const size_t n = (size_t)width * height;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     {
@@ -1850,14 +1779,15 @@ extern "C" hipError_t r1_launch_resolve(const R1ResolveArgs *args, hipStream_t s
 }
 
 extern "C" hipError_t r1_launch_assemble(const void *blocks, void *rgb, int width, int height, int tile_w, int tile_h, int tiles_x,
-                                         int tiles_total, int num_shards, int tiles_per_shard, size_t shard_stride, hipStream_t stream)
+                                         int tiles_total, int num_shards, int tiles_per_shard, size_t shard_stride, void *total_rays,
+                                         hipStream_t stream)
 {
     const size_t n = (size_t)width * height;
     int grid = (int)((n + 255) / 256);
     if (grid > 8192)
         grid = 8192;
     hipLaunchKernelGGL(r1_assemble_kernel, dim3(grid), dim3(256), 0, stream, (const uint8_t *)blocks, (uint8_t *)rgb, width, height,
-                       tile_w, tile_h, tiles_x, tiles_total, num_shards, tiles_per_shard, shard_stride);
+                       tile_w, tile_h, tiles_x, tiles_total, num_shards, tiles_per_shard, shard_stride, (unsigned long long *)total_rays);
     return hipGetLastError();
 }
 

@@ -246,7 +246,8 @@ extern "C" int r1_multi_render(r1_multi *m, const r1_params *params, uint8_t *rg
     const size_t block = r1_shard_block_bytes(&p);
     if (block == 0)
         return R1_EINVAL;
-    const size_t record = block + 8; // + the shard's uint64 ray count: pixels and counts travel in one collective
+    const size_t record = r1_shard_record_bytes(&p); // block, padded to 8 bytes, + the shard's uint64 ray count: pixels and counts travel in one collective
+    const size_t trailer = record - 8;
     const size_t rgb_bytes = (size_t)p.width * p.height * 3;
     if (record > m->record_cap)
     {
@@ -275,39 +276,86 @@ extern "C" int r1_multi_render(r1_multi *m, const r1_params *params, uint8_t *rg
         m->rgb_cap = rgb_bytes;
     }
     // 1. every device traces + resolves its tiles into its record (latency-mode kernels: one frame, the caller waits)
-    for (int i = 0; i < m->n; ++i)
+    // From the first enqueue on, a failure must not leave work in flight behind the caller's back: the error is
+    // remembered, an open RCCL group is closed, every device's stream is drained, and only then does the call return.
+    int first_rc = R1_OK;
+    auto drain = [&](int rc) {
+        for (int i = 0; i < m->n; ++i)
+            if (hipSetDevice(m->device[i]) == hipSuccess)
+                (void)hipStreamSynchronize(m->stream[i]);
+        return rc;
+    };
+    for (int i = 0; i < m->n && first_rc == R1_OK; ++i)
     {
         r1_params q = p;
         q.shard = i;
-        R1M_HIP(hipSetDevice(m->device[i]));
-        R1M_HIP(hipEventRecord(m->ev0[i], m->stream[i]));
-        const int rc = r1_render_shard_device_once(m->ctx[i], &q, m->d_record[i], (char *)m->d_record[i] + block, m->stream[i]);
-        if (rc != R1_OK)
-            return rc;
+        hipError_t he = hipSetDevice(m->device[i]);
+        if (he == hipSuccess)
+            he = hipEventRecord(m->ev0[i], m->stream[i]);
+        if (he != hipSuccess)
+        {
+            r1_set_error("r1_multi_render: device %d: %s", m->device[i], hipGetErrorString(he));
+            first_rc = R1_EHIP;
+            break;
+        }
+        first_rc = r1_render_shard_device_once(m->ctx[i], &q, m->d_record[i], (char *)m->d_record[i] + trailer, m->stream[i]);
     }
+    if (first_rc != R1_OK)
+        return drain(first_rc);
     // 2. the one exchange step of the frame: all-gather of the records over xGMI
-    R1M_NCCL(m, m->rccl.GroupStart());
-    for (int i = 0; i < m->n; ++i)
-        R1M_NCCL(m, m->rccl.AllGather(m->d_record[i], m->d_gathered[i], record, R1_NCCL_UINT8, m->comm[i], m->stream[i]));
-    R1M_NCCL(m, m->rccl.GroupEnd());
+    ncclResult_t nr = m->rccl.GroupStart();
+    if (nr != 0)
+    {
+        r1_set_error("ncclGroupStart failed: %s", m->rccl.GetErrorString(nr));
+        return drain(R1_EHIP);
+    }
+    for (int i = 0; i < m->n && nr == 0; ++i)
+        nr = m->rccl.AllGather(m->d_record[i], m->d_gathered[i], record, R1_NCCL_UINT8, m->comm[i], m->stream[i]);
+    const ncclResult_t ne = m->rccl.GroupEnd(); // always closed, also after a failed enqueue
+    if (nr != 0 || ne != 0)
+    {
+        r1_set_error("ncclAllGather of the frame's records failed: %s", m->rccl.GetErrorString(nr != 0 ? nr : ne));
+        return drain(R1_EHIP);
+    }
     for (int i = 0; i < m->n; ++i)
     {
-        R1M_HIP(hipSetDevice(m->device[i]));
-        R1M_HIP(hipEventRecord(m->ev1[i], m->stream[i]));
+        if (hipSetDevice(m->device[i]) != hipSuccess || hipEventRecord(m->ev1[i], m->stream[i]) != hipSuccess)
+        {
+            r1_set_error("r1_multi_render: event record failed on device %d", m->device[i]);
+            return drain(R1_EHIP);
+        }
     }
     // 3. device 0 scatters the gathered tiles into the row-major image; one copy to the host (+ the N counts)
-    R1M_HIP(hipSetDevice(m->device[0]));
-    int rc = r1_assemble_device_strided(m->ctx[0], &p, m->d_gathered[0], record, m->d_rgb, m->stream[0]);
-    if (rc != R1_OK)
-        return rc;
     std::vector<uint64_t> counts((size_t)m->n, 0);
-    R1M_HIP(hipMemcpyAsync(rgb_out, m->d_rgb, rgb_bytes, hipMemcpyDeviceToHost, m->stream[0]));
-    R1M_HIP(hipMemcpy2DAsync(counts.data(), 8, (char *)m->d_gathered[0] + block, record, 8, (size_t)m->n, hipMemcpyDeviceToHost, m->stream[0]));
-    R1M_HIP(hipStreamSynchronize(m->stream[0]));
-    for (int i = 1; i < m->n; ++i) // the other devices' gathers are complete before their streams are reused
     {
-        R1M_HIP(hipSetDevice(m->device[i]));
-        R1M_HIP(hipStreamSynchronize(m->stream[i]));
+        hipError_t he = hipSetDevice(m->device[0]);
+        int rc = he == hipSuccess ? r1_assemble_device_strided(m->ctx[0], &p, m->d_gathered[0], record, m->d_rgb, m->stream[0]) : R1_EHIP;
+        if (rc == R1_OK)
+        {
+            he = hipMemcpyAsync(rgb_out, m->d_rgb, rgb_bytes, hipMemcpyDeviceToHost, m->stream[0]);
+            if (he == hipSuccess)
+                he = hipMemcpy2DAsync(counts.data(), 8, (char *)m->d_gathered[0] + trailer, record, 8, (size_t)m->n, hipMemcpyDeviceToHost, m->stream[0]);
+            if (he != hipSuccess)
+            {
+                r1_set_error("r1_multi_render: copy to the host failed: %s", hipGetErrorString(he));
+                rc = R1_EHIP;
+            }
+        }
+        // every device's stream is idle before the call returns (the other devices' gathers are complete before their
+        // records are reused), whether the frame succeeded or not
+        for (int i = 0; i < m->n; ++i)
+        {
+            he = hipSetDevice(m->device[i]);
+            if (he == hipSuccess)
+                he = hipStreamSynchronize(m->stream[i]);
+            if (he != hipSuccess && rc == R1_OK)
+            {
+                r1_set_error("r1_multi_render: device %d: %s", m->device[i], hipGetErrorString(he));
+                rc = R1_EHIP;
+            }
+        }
+        if (rc != R1_OK)
+            return rc;
     }
     uint64_t rays = 0;
     for (uint64_t c : counts)

@@ -298,8 +298,12 @@ static void log_json(const char *version, const char *scene, const RESULT *resul
     const double rays_per_dev_s = dev > 0 ? rays / dev : 0;
     fprintf(f, "],\n \"mrays_per_s\": %.3f, \"device_mrays_per_s\": %.3f, \"spheres_padded\": %d, \"spheres_active\": %d,\n", el > 0 ? rays / el / 1e6 : 0.0,
             rays_per_dev_s / 1e6, g_last_info.spheres_padded, g_last_info.spheres_active);
-    fprintf(f, " \"algorithmic_bytes_per_ray\": %.0f, \"hbm_algorithmic_fraction_of_8TBs\": %.4f, \"fp32_vector_fraction_of_157TFs\": %.4f}\n", per_ray,
-            rays_per_dev_s * per_ray / 8.0e12 / (double)g_devices, rays_per_dev_s * per_ray / 157.3e12 / (double)g_devices);
+    // the two device-only fractions are null for the CPU stages (devices == 0): nothing ran on a GPU
+    if (g_devices > 0)
+        fprintf(f, " \"algorithmic_bytes_per_ray\": %.0f, \"hbm_algorithmic_fraction_of_8TBs\": %.4f, \"fp32_vector_fraction_of_157TFs\": %.4f}\n", per_ray,
+                rays_per_dev_s * per_ray / 8.0e12 / (double)g_devices, rays_per_dev_s * per_ray / 157.3e12 / (double)g_devices);
+    else
+        fprintf(f, " \"algorithmic_bytes_per_ray\": %.0f, \"hbm_algorithmic_fraction_of_8TBs\": null, \"fp32_vector_fraction_of_157TFs\": null}\n", per_ray);
     fclose(f);
 }
 

@@ -56,12 +56,13 @@ def assemble(blocks, width, height, num_shards, tile_w=32, tile_h=32):
     return out
 
 
-RECORD_TRAILER = 8  # bytes appended to a shard block: its uint64 ray count
+RECORD_TRAILER = 8  # bytes at the end of a shard's record: its uint64 ray count
 
 
 def record_bytes(width, height, num_shards, tile_w=32, tile_h=32):
-    """One rank's gather record: the dense tile block followed by the 8-byte ray count."""
-    return block_bytes(width, height, num_shards, tile_w, tile_h) + RECORD_TRAILER
+    """One rank's gather record (include/rays1.h r1_shard_record_bytes): the dense tile block, padded to a
+    multiple of 8 bytes so that the count is an aligned 64-bit word for any tile size, then the 8-byte ray count."""
+    return ((block_bytes(width, height, num_shards, tile_w, tile_h) + 7) & ~7) + RECORD_TRAILER
 
 
 def gather_records(dist, record, gathered):
@@ -74,13 +75,17 @@ def gather_records(dist, record, gathered):
 
 def make_record(block, rays):
     """numpy: dense tile block (flat uint8) + ray count -> one gather record."""
-    return np.concatenate([np.asarray(block, np.uint8), np.array([rays], np.uint64).view(np.uint8)])
+    block = np.asarray(block, np.uint8)
+    pad = np.zeros((-block.size) % 8, np.uint8)
+    return np.concatenate([block, pad, np.array([rays], np.uint64).view(np.uint8)])
 
 
 def assemble_records(gathered, width, height, num_shards, tile_w=32, tile_h=32):
     """Host mirror of r1_assemble_device_strided over gathered records; returns (image, total rays)."""
     g = np.asarray(gathered, np.uint8).reshape(num_shards, -1)
-    blocks = g[:, :-RECORD_TRAILER].reshape(-1)
+    nblock = block_bytes(width, height, num_shards, tile_w, tile_h)
+    assert g.shape[1] == record_bytes(width, height, num_shards, tile_w, tile_h)
+    blocks = g[:, :nblock].reshape(-1)
     rays = int(np.ascontiguousarray(g[:, -RECORD_TRAILER:]).view(np.uint64).sum())
     return assemble(blocks, width, height, num_shards, tile_w, tile_h), rays
 

@@ -101,3 +101,37 @@ def test_bench_defaults_are_the_contracts():
     steps = int(re.search(r'"--steps", type=int, default=(\d+)', src).group(1))
     warmup = int(re.search(r'"--warmup", type=int, default=(\d+)', src).group(1))
     assert 10 <= steps <= 2000 and 1 <= warmup <= steps
+
+
+def test_bare_gpus_n_launches_fresh_ranks_before_touching_the_gpu(monkeypatch):
+    """`python bench.py --gpus N` (no launcher): the parent starts torch.distributed.run with one rank per GPU on
+    127.0.0.1 and relays the exit code — without importing torch or librays1 itself (it used to exit)."""
+    import subprocess
+    import sys
+    probe = subprocess.run([sys.executable, "-c", "import sys; sys.argv = ['bench.py', '--gpus', '4', '--steps', '7']\n"
+                            "import bench, subprocess\n"
+                            "seen = {}\n"
+                            "def fake(cmd, **kw):\n"
+                            "    seen['cmd'] = cmd; seen['env'] = kw.get('env', {})\n"
+                            "    class R: returncode = 17\n"
+                            "    return R()\n"
+                            "subprocess.run = fake\n"
+                            "rc = bench.main()\n"
+                            "assert rc == 17, rc\n"
+                            "c = seen['cmd']\n"
+                            "assert c[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node' in c and c[c.index('--nproc-per-node') + 1] == '4'\n"
+                            "assert c[c.index('--master-addr') + 1] == '127.0.0.1' and c[-4:] == ['--gpus', '4', '--steps', '7']\n"
+                            "assert seen['env'].get('HSA_ENABLE_IPC_MODE_LEGACY') == '0'\n"
+                            "assert 'torch' not in sys.modules and 'rays1bench_amd' not in sys.modules\n"
+                            "print('ok')"], capture_output=True, text=True, cwd=ROOT, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")})
+    assert probe.returncode == 0 and probe.stdout.strip() == "ok", probe.stderr[-1500:]
+
+
+def test_hardware_queue_budget_is_explicit_and_below_the_cliff():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'os.environ["GPU_MAX_HW_QUEUES"] = str(q)' in src and "setdefault(\"GPU_MAX_HW_QUEUES\"" not in src
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    assert bench.INFLIGHT_SINGLE <= bench.QUEUES_SINGLE < bench.QUEUES_CLIFF and bench.INFLIGHT_RANK < bench.QUEUES_RANK < bench.QUEUES_CLIFF

@@ -273,6 +273,69 @@ def test_device_resident_shard_and_assemble(renderer):
     assert img_h.tobytes() == full.tobytes() and rays_h == full_rays
 
 
+def test_records_with_odd_tiles_are_aligned_and_sum_their_counts(renderer):
+    """with 5x7 tiles a shard block is not a multiple of 8 bytes; the record pads it so that the uint64 ray
+    count behind it stays aligned (r1_shard_record_bytes), an unaligned count pointer is R1_EINVAL, and
+    r1_assemble_device_records scatters the blocks and sums the shards' counts next to the image."""
+    torch = pytest.importorskip("torch")
+    from rays1bench_amd import sharding
+    w, h, spp, shards, tw, th = 93, 61, 3, 3, 5, 7
+    renderer.set_scene(r1.create_small_scene(w, h))
+    full, full_rays, _ = renderer.render(mp(w, h, spp, 77, tile_w=tw, tile_h=th))
+    p0 = mp(w, h, spp, 77, tile_w=tw, tile_h=th, shard=0, num_shards=shards)
+    nbytes, rec = binding.shard_block_bytes(p0), binding.shard_record_bytes(p0)
+    assert nbytes % 8 != 0 and rec % 8 == 0 and rec == ((nbytes + 7) & ~7) + 8 == sharding.record_bytes(w, h, shards, tw, th)
+    records = torch.zeros((shards, rec), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    with pytest.raises(r1.R1Error) as e:
+        renderer.render_shard_device(p0, records[0].data_ptr(), records[0].data_ptr() + nbytes, stream)  # unaligned count
+    assert e.value.code == binding.R1_EINVAL
+    for s_ in range(shards):
+        q = mp(w, h, spp, 77, tile_w=tw, tile_h=th, shard=s_, num_shards=shards)
+        renderer.render_shard_device(q, records[s_].data_ptr(), records[s_].data_ptr() + rec - 8, stream)
+    img_pad = (w * h * 3 + 7) & ~7
+    out = torch.zeros(img_pad + 8, dtype=torch.uint8, device="cuda")
+    renderer.assemble_device_records(p0, records.data_ptr(), out.data_ptr(), out.data_ptr() + img_pad, stream)
+    torch.cuda.synchronize()
+    assert out[:w * h * 3].cpu().numpy().tobytes() == full.tobytes()
+    assert int(out[img_pad:].view(torch.int64).item()) == full_rays == sharding.total_rays(records.view(-1), shards)
+    img_h, rays_h = sharding.assemble_records(records.cpu().numpy(), w, h, shards, tw, th)
+    assert img_h.tobytes() == full.tobytes() and rays_h == full_rays
+
+
+def test_render_async_lands_the_frame_in_page_locked_host_memory(renderer):
+    """r1_render_async (frames in flight whose results land on the host, bench.py's `value`): same pixels and count as
+    the synchronous r1_render, through the throughput kernels, several frames in flight on several contexts."""
+    w, h, spp = 210, 130, 5
+    frames = []
+    sc = r1.create_large_scene(w, h)
+    renderer.set_scene(sc)
+    want = {seed: renderer.render(mp(w, h, spp, seed))[:2] for seed in (5, 6, 7)}
+    ctxs = [r1.Renderer(0) for _ in range(3)]
+    for c, seed in zip(ctxs, (5, 6, 7)):
+        c.set_scene(sc)
+        hf = binding.HostFrame(w, h)
+        c.render_async(mp(w, h, spp, seed), hf)  # the context's own stream
+        frames.append((c, hf, seed))
+    for c, hf, seed in frames:
+        c.sync()
+        assert hf.rays == want[seed][1]
+        assert hf.image.tobytes() == want[seed][0].tobytes()
+    # a second frame through the same context and buffer; sharded frames are refused
+    c, hf, _ = frames[0]
+    c.render_async(mp(w, h, spp, 6), hf)
+    c.sync()
+    assert hf.rays == want[6][1] and hf.image.tobytes() == want[6][0].tobytes()
+    with pytest.raises(r1.R1Error):
+        c.render_async(mp(w, h, spp, 6, shard=0, num_shards=2), hf)
+    c.render_frame_device(mp(w, h, spp, 7))  # no host buffers: the frame stays on the device
+    c.sync()
+    assert hf.rays == want[6][1]
+    for c, hf, _ in frames:
+        c.close()
+        hf.close()
+
+
 # ---- big scenes (BASELINE config 5 shape: the large generator scaled up) -------------------------
 
 
@@ -401,22 +464,34 @@ def test_bench_two_ranks_rehearsal_gathers_the_unsharded_frame():
     --check compares the gathered + assembled image and ray count with an unsharded render."""
     if KERNEL["variant"] != binding.VARIANT_DEFAULT:
         pytest.skip("runs the program's own kernel choice: once is enough")
-    import socket
     import subprocess
     import sys
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     env = dict(os.environ, R1_BENCH_DEVICE="0")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+    # the BARE entry: bench.py starts its two ranks itself (fresh processes, before it touches HIP) and relays their line
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
                           "--steps", "6", "--warmup", "2", "--inflight", "4", "--check", "--width", "300", "--height", "200", "--spp", "4"],
                          capture_output=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     line = json.loads(out.stdout.decode().strip().splitlines()[-1])
     assert line["check"] is True and line["n_gpus"] == 2 and line["scaling"] == "strong"
+    assert "to page-locked HOST memory" in line["config"]["value_mode"]
     assert "cpu_baseline" not in line and line["roofline"]["bound"] == "valu" and 0 < line["roofline"]["frac"] <= 1
+    assert line["value_device_resident"]["value"] > 0
+
+
+def test_bench_in_process_multi_mode_one_gpu():
+    """bench.py --multi inproc: ONE process drives the GPUs through r1_multi_* (ncclCommInitAll + one ncclAllGather per
+    frame); on the one-GPU box that is a one-rank communicator — the whole path, collective included."""
+    if KERNEL["variant"] != binding.VARIANT_DEFAULT:
+        pytest.skip("runs the program's own kernel choice: once is enough")
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--multi", "inproc", "--steps", "5", "--warmup", "2",
+                          "--check", "--width", "300", "--height", "200", "--spp", "4"], capture_output=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    assert line["check"] is True and line["n_gpus"] == 1 and "r1_multi" in line["config"]["parallelism"]
+    assert line["value"] > 0 and abs(line["value"] - line["config"]["rays_per_step"] / line["ms_per_step"] / 1e3) < 1e-6 * line["value"]
 
 
 # ---- sphere-count edges: empty scene, last small-kernel scene, first big-kernel scene ------------

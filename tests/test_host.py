@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/rays1.h but not exported"
     assert declared == {s[0] for s in binding.SYMBOLS}
-    assert L.r1_abi_version() == 2
+    assert L.r1_abi_version() == 3
 
 
 def test_struct_layouts_match_header():
@@ -188,6 +188,11 @@ def _run_backend(tmp_path, backend, w, h, spp):
         assert tga[:18] == bytes([0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, w & 255, w >> 8, h & 255, h >> 8, 24, 0])
         res[name] = (rays, np.frombuffer(tga[18:], np.uint8).reshape(h, w, 3)[:, :, ::-1])
         assert re.fullmatch(rf"{backend}\|\d+\.\d{{3}}s\|{rays}\|\d+\.\d{{3}} mrays/s\|", open(os.path.join(tmp_path, f"out_{name}.txt")).read())
+        # the JSON record parses (the device-only fractions were 0/0 = -nan with devices == 0) and says what ran
+        import json
+        rec = json.load(open(os.path.join(tmp_path, f"out_{name}.json")))
+        assert rec["devices"] == 0 and rec["version"] == backend and rec["runs"][0]["num_rays"] == rays
+        assert rec["hbm_algorithmic_fraction_of_8TBs"] is None and rec["fp32_vector_fraction_of_157TFs"] is None
     return res
 
 

@@ -8,6 +8,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rays1bench_amd as r1
 from rays1bench_amd import binding
+if os.environ.get("R1_LIB"):  # tools only: another build of the library (e.g. lib/librays1_tuning.so), chosen explicitly
+    binding.set_lib_path(os.environ["R1_LIB"])
 
 args = sys.argv[1:]
 scene = args[0] if args else "large"
@@ -23,8 +25,7 @@ for v in (binding.VARIANT_BVH, binding.VARIANT_BVH_STATS):
         img, rays, secs = rend.render(r1.make_params(w, h, spp, 10001, variant=v))
     print(f"variant {v}: rays {rays} device {rend.last_timing()[1]:.3f} ms")
 st = rend.last_stats()
-leaf_lane_trips = st["cycles_pass1"] >> 32          # slot [5]: sphere-pair tests (low 32 bits) | leaf trips summed over lanes << 32
-st["cycles_pass1"] &= 0xFFFFFFFF
+leaf_lane_trips = st["leaf_lane_trips"]             # slot [14]: leaf trips summed over lanes; slot [5] ("cycles_pass1"): sphere-pair tests
 info = rend.launch_info()
 waves = info["blocks"] * 4
 it = st["wave_iterations"]

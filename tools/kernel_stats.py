@@ -8,6 +8,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rays1bench_amd as r1
 from rays1bench_amd import binding
+if os.environ.get("R1_LIB"):  # tools only: another build of the library (e.g. lib/librays1_tuning.so), chosen explicitly
+    binding.set_lib_path(os.environ["R1_LIB"])
 
 scene = sys.argv[1] if len(sys.argv) > 1 else "large"
 w, h, spp = (int(x) for x in (sys.argv[2:5] if len(sys.argv) > 4 else (1200, 800, 10)))

@@ -8,6 +8,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rays1bench_amd as r1
 from rays1bench_amd import binding
+if os.environ.get("R1_LIB"):  # tools only: another build of the library (e.g. lib/librays1_tuning.so), chosen explicitly
+    binding.set_lib_path(os.environ["R1_LIB"])
 
 w = h = 64
 sc = r1.create_large_scene(w, h)

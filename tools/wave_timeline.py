@@ -10,6 +10,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rays1bench_amd as r1
 from rays1bench_amd import binding
+if os.environ.get("R1_LIB"):  # tools only: another build of the library (e.g. lib/librays1_tuning.so), chosen explicitly
+    binding.set_lib_path(os.environ["R1_LIB"])
 
 args = sys.argv[1:]
 scene = args[0] if args else "large"
