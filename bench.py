@@ -40,6 +40,7 @@ VALU_ISSUE_PEAK_T = 1024 * 2.4e9 / 2 / 1e12  # wave-instructions/s: 256 CUs x 4 
 # therefore keep 16 frames in flight on 18 queues; one process driving N GPUs in-process runs one frame at a time.
 INFLIGHT_SINGLE, QUEUES_SINGLE = 20, 20
 INFLIGHT_RANK, QUEUES_RANK = 16, 18
+INFLIGHT_RANK_BATCHED = 8   # launches in flight per rank when every launch carries a batch of frames
 QUEUES_CLIFF = 24
 
 
@@ -212,6 +213,9 @@ def parse_args(argv=None):
                     help="frames in flight, each on its own stream + context workspace: later frames' workgroups fill "
                          "the CUs that a frame's last long bounce chains leave idle (1 = one frame at a time; "
                          f"0 = default: {INFLIGHT_SINGLE} on one GPU, {INFLIGHT_RANK} per rank when RCCL needs hardware queues of its own)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="frames per launch (r1_render_batch_async: the persistent waves flow from one frame into the next, so a launch's "
+                         "ramp and drain are paid once per batch); 0 = the mode's default")
     ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this run (0 = the mode's measured default)")
     ap.add_argument("--emulate-shards", type=int, default=0,
                     help="tuning aid: render only shard 0 of K on one GPU, no collective (per-rank load of a K-GPU run)")
@@ -341,10 +345,18 @@ def run_ranks(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n = world
     uses_rccl = (n > 1 and args.backend == "nccl") or args.rccl_selftest
+    shards_ = max(n, args.emulate_shards, 1)
+    # Frames per launch (r1_render_shard_device_batch).  Measured per-rank rates on one MI355X carrying rank 0's tiles
+    # (profiles/r03/batch_sweep.txt): a rank's share of one frame is too small a launch at N >= 4 (8 shards: 23.3 Grays/s
+    # per rank with one frame per launch, 29.4 with 8; 4 shards: 28.2 -> 30.5; 2 shards: 32.0 either way; whole frames at
+    # N = 1: 32.5 alone, 30-31 batched), so N >= 3 ranks batch N frames per launch — when the run is long enough to keep
+    # ~16 launches busy (a 20-step run is better off with 20 small launches than with 3 large ones).
+    if args.batch <= 0:
+        args.batch = max(1, min(shards_, args.steps // 16)) if shards_ >= 3 and not args.pixel_mode else 1
     if args.inflight <= 0:
-        args.inflight = INFLIGHT_RANK if (n > 1 or args.emulate_shards > 1) else INFLIGHT_SINGLE
+        args.inflight = INFLIGHT_SINGLE if shards_ == 1 else (INFLIGHT_RANK if args.batch == 1 else INFLIGHT_RANK_BATCHED)
     extra = QUEUES_RANK - INFLIGHT_RANK if uses_rccl else 0
-    args.inflight = max(1, min(args.inflight, QUEUES_CLIFF - 1 - extra))  # frames' queues + RCCL's stay under the cliff
+    args.inflight = max(1, min(args.inflight, QUEUES_CLIFF - 1 - extra))  # launches' queues + RCCL's stay under the cliff
     set_hw_queues(args, args.inflight + extra)
     import numpy as np
     import torch
@@ -384,8 +396,14 @@ def run_ranks(args):
     img_pad = (img_bytes + 7) & ~7
     host_copy = [not args.no_host_copy]
 
+    B = max(1, args.batch)  # frames per launch (r1_render_batch_async): the waves flow from one frame into the next
+    if args.pixel_mode:
+        B = 1           # PIXEL mode has no batch form
+    frec = binding.frame_record_bytes(p)  # image (padded to 8 bytes) + uint64 ray count
+
     class Slot:
-        """One frame in flight: its own context (stream-ordered workspace), stream, device buffers and page-locked host frame."""
+        """One launch in flight: its own context (stream-ordered workspace), stream, device buffers and page-locked host
+        frames.  step() adds a frame to the slot's pending batch; the batch is launched when it is full (or at a fence)."""
 
         def __init__(self):
             self.rend = r1.Renderer(local_rank)
@@ -394,95 +412,111 @@ def run_ranks(args):
             self.rend.set_scene(self.scene)
             if args.pixel_mode:
                 self.rend.set_pixel_mode(True)
-            self.host = binding.HostFrame(w, h)  # pixels + ray count land here
+            self.host = binding.HostFrames(w, h, B)  # pixels + ray counts land here
+            self.host_t = torch.from_numpy(self.host._all)  # torch view of the page-locked frames: target of the non-blocking copies
             self.stream = torch.cuda.Stream(device=dev)
+            self.pending, self.last = 0, 0
             if sharded or args.pixel_mode:
-                self.record = torch.zeros(record_bytes, dtype=torch.uint8, device=dev)
-                self.gathered = torch.zeros(n * record_bytes, dtype=torch.uint8, device=dev) if n > 1 else self.record
-                # row-major image with the frame's ray count behind it: one copy brings both to the host
-                self.image = torch.zeros(img_pad + 8, dtype=torch.uint8, device=dev)
+                self.records = torch.zeros(B * record_bytes, dtype=torch.uint8, device=dev)
+                self.gathered = torch.zeros(n * B * record_bytes, dtype=torch.uint8, device=dev) if n > 1 else self.records
+                self.frames = torch.zeros(B * frec, dtype=torch.uint8, device=dev)  # assembled frame records: one copy brings them to the host
+                if args.rccl_selftest and n == 1:
+                    self.selftest = torch.zeros(B * record_bytes, dtype=torch.uint8, device=dev)
 
         def step(self):
+            self.pending += 1
+            if self.pending == B:
+                self.launch()
+
+        def launch(self):
+            k, self.pending = self.pending, 0
+            if k == 0:
+                return
+            self.last = k
             sp = self.stream.cuda_stream
             if not (sharded or args.pixel_mode):
-                # whole frame on this GPU: trace + resolve straight into the row-major image, then image + count -> host
-                if host_copy[0]:
-                    self.rend.render_async(p, self.host, sp)
+                # whole frames on this GPU: trace + resolve straight into row-major frame records, then ONE copy to the host
+                if B == 1:
+                    self.rend.render_async(p, self.host, sp) if host_copy[0] else self.rend.render_frame_device(p, sp)
                 else:
-                    self.rend.render_frame_device(p, sp)
+                    self.rend.render_batch_async(p, k, self.host if host_copy[0] else None, 0, sp)
                 return
             with torch.cuda.stream(self.stream):
-                self.rend.render_shard_device(p, self.record.data_ptr(), self.record.data_ptr() + trailer, sp)
-                if dist is not None and (n > 1 or args.rccl_selftest):
-                    if n > 1:
-                        sharding.gather_records(dist, self.record, self.gathered)
-                    else:
-                        dist.all_gather_into_tensor(self.selftest, self.record)
+                if args.pixel_mode:
+                    self.rend.render_shard_device(p, self.records.data_ptr(), self.records.data_ptr() + trailer, sp)
+                else:
+                    self.rend.render_shard_device_batch(p, k, self.records.data_ptr(), 0, sp)
+                if n > 1:  # the one exchange step of the batch: [rank][frame][record]
+                    sharding.gather_records(dist, self.records[:k * record_bytes], self.gathered[:n * k * record_bytes])
+                elif args.rccl_selftest:
+                    dist.all_gather_into_tensor(self.selftest[:k * record_bytes], self.records[:k * record_bytes])
                 if n > 1 or not sharded:
-                    self.rend.assemble_device_records(p, self.gathered.data_ptr(), self.image.data_ptr(), self.image.data_ptr() + img_pad, sp)
+                    self.rend.assemble_device_records_batch(p, k, self.gathered.data_ptr(), self.frames.data_ptr(), sp)
                     if host_copy[0]:
-                        self.host_t.copy_(self.image, non_blocking=True)
+                        self.host_t[:k * frec].copy_(self.frames[:k * frec], non_blocking=True)
                 elif host_copy[0]:
-                    # emulated rank of a K-GPU run: its own record stands in for the gathered image (same bytes per frame / K)
-                    self.host_t[:record_bytes].copy_(self.record, non_blocking=True)
+                    # emulated rank of a K-GPU run: its own records stand in for the gathered frames (same bytes per frame / K)
+                    self.host_t[:k * record_bytes].copy_(self.records[:k * record_bytes], non_blocking=True)
 
         def frame_rays(self):
-            """Whole-frame ray count as it landed (host) or as the device holds it."""
+            """Whole-frame ray count of the slot's last launch as it landed (host) or as the device holds it."""
             torch.cuda.synchronize()
-            if not (sharded or args.pixel_mode):
-                if not host_copy[0]:  # device-resident run: bring one frame home to read its count
-                    self.rend.render_async(p, self.host, self.stream.cuda_stream)
-                    torch.cuda.synchronize()
-                return self.host.rays
-            if n > 1 or not sharded:
-                return int(self.image[img_pad:].view(torch.int64).item())
-            return int(self.record[trailer:].view(torch.int64).item())
+            if sharded and n == 1:
+                return int(self.records[trailer:record_bytes].view(torch.int64).item())
+            if not host_copy[0]:  # device-resident run: bring the frames home to read the count
+                if sharded or args.pixel_mode:
+                    self.host_t[:frec].copy_(self.frames[:frec])
+                else:
+                    self.rend.render_batch_async(p, 1, self.host, 0, self.stream.cuda_stream)
+                torch.cuda.synchronize()
+            return self.host.rays(0)
 
         def local_rays(self):
             torch.cuda.synchronize()
             if not (sharded or args.pixel_mode):
                 return self.frame_rays()
-            return int(self.record[trailer:].view(torch.int64).item())
+            return int(self.records[trailer:record_bytes].view(torch.int64).item())
 
     slots = [Slot() for _ in range(max(1, args.inflight))]
-    for sl in slots:
-        if sharded or args.pixel_mode:
-            # torch view of the slot's page-locked host frame (r1_host_alloc): target of the non-blocking copies
-            sl.host_t = torch.from_numpy(sl.host._all)
-            if args.rccl_selftest and n == 1:
-                sl.selftest = torch.zeros(record_bytes, dtype=torch.uint8, device=dev)
     rend = slots[0].rend
     counter = [0]
 
     def step():
-        slots[counter[0] % len(slots)].step()
+        slots[(counter[0] // B) % len(slots)].step()
         counter[0] += 1
 
+    def flush():
+        for sl in slots:
+            sl.launch()  # a partial last batch
+        counter[0] = 0
+
     def fence():
+        flush()
         torch.cuda.synchronize()
         if n > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
     def timed(steps, with_events=False):
-        """Time EXACTLY `steps` steps between two fences; max over ranks.  Returns (elapsed, submit, events)."""
+        """Time EXACTLY `steps` steps (frames) between two fences; max over ranks.  Returns (elapsed, submit, events)."""
         if with_events:
             for sl in slots:
-                sl.rend.timing_begin(steps // len(slots) + 2)  # frames this slot will carry
+                sl.rend.timing_begin(steps // (B * len(slots)) + 3)  # launches this slot will carry
         fence()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        flush()
         submit = time.perf_counter() - t0  # host time to enqueue the frames (must stay below `elapsed`)
         fence()
         elapsed = time.perf_counter() - t0
         ev = None
         if with_events:
-            trace_ms, total_ms, frames = 0.0, 0.0, 0
+            trace_ms, total_ms, launches = 0.0, 0.0, 0
             for sl in slots:
                 a, b, c = sl.rend.timing_end()
-                trace_ms, total_ms, frames = trace_ms + a, total_ms + b, frames + c
-            ev = (trace_ms, total_ms, frames)
+                trace_ms, total_ms, launches = trace_ms + a, total_ms + b, launches + c
+            ev = (trace_ms, total_ms, launches)
         if n > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -494,18 +528,20 @@ def run_ranks(args):
     # hardware queues lazily, ~7 ms each, during the first ~40 submissions on 20 streams (tools/submit_times.py:
     # five such stalls in the first pass, three in the second, none afterwards).
     for _ in range(2):
-        for sl in slots:
-            sl.step()
+        for _ in range(B * len(slots)):
+            step()
         fence()
     for _ in range(args.warmup):
         step()
     fence()
     slots[0].step()
+    slots[0].launch()
     rays_per_step = slots[0].frame_rays()  # whole frame: the count that landed on the host
     if sharded and n == 1:
         rays_per_step = slots[0].local_rays()  # emulated rank: its share only
 
-    elapsed, submit, (trace_ms_sum, total_ms_sum, frames) = timed(args.steps, with_events=True)
+    elapsed, submit, (trace_ms_sum, total_ms_sum, launches) = timed(args.steps, with_events=True)
+    frames = args.steps
     value = rays_per_step * args.steps / elapsed / 1e6
     info = rend.launch_info()
     local_rays = slots[0].local_rays()  # this rank's rays: the work of ITS kernel launches
@@ -513,11 +549,10 @@ def run_ranks(args):
     check = None
     if args.check and not (sharded and n == 1):
         torch.cuda.synchronize()
-        if sharded or args.pixel_mode:
-            got = (slots[0].host._all[:img_bytes] if host_copy[0] else slots[0].image[:img_bytes].cpu().numpy()).tobytes()
-        else:
-            slots[0].frame_rays()  # (device-resident run: brings one frame home)
-            got = slots[0].host.image.tobytes()
+        slots[0].step()
+        slots[0].launch()
+        assert slots[0].frame_rays() == rays_per_step  # (device-resident run: brings the frame home)
+        got = slots[0].host.image(0).tobytes()
         ref = np.zeros((h, w, 3), np.uint8)
         ref_rays, _ = rend.render_into(r1.make_params(w, h, spp, args.seed, variant=args.variant), ref)
         check = bool(got == ref.tobytes() and rays_per_step == ref_rays)
@@ -527,12 +562,12 @@ def run_ranks(args):
     if host_copy[0] and not args.no_extras:
         # the same frames left in HBM: what the copies to the host cost
         host_copy[0] = False
-        for _ in range(len(slots)):
+        for _ in range(B * len(slots)):
             step()
-        steps2 = max(len(slots), args.steps // 2)
+        steps2 = max(B * len(slots), args.steps // 2)
         e2, _, _ = timed(steps2)
         resident = {"value": rays_per_step * steps2 / e2 / 1e6, "unit": "mrays/s", "steps": steps2, "ms_per_step": e2 / steps2 * 1e3,
-                    "mode": f"{len(slots)} frames in flight, image and ray count left in HBM (round 2's headline mode)"}
+                    "mode": f"{len(slots) * B} frames in flight, images and ray counts left in HBM (round 2's headline mode)"}
         host_copy[0] = True
 
     # The same workload through the exhaustive sweep (the reference's algorithm: every ray against
@@ -541,8 +576,8 @@ def run_ranks(args):
     if n == 1 and args.variant == 0 and info["kernel"] == 4 and not sharded and info["spheres_active"] <= 1023 and not args.no_extras:
         p_main = p
         p = r1.make_params(w, h, spp, args.seed, shard=0, num_shards=1, variant=binding.VARIANT_PREFILTER)
-        sweep_steps = max(len(slots), args.steps // 2)
-        for _ in range(len(slots)):
+        sweep_steps = max(B * len(slots), args.steps // 2)
+        for _ in range(B * len(slots)):
             step()
         sweep_elapsed, _, _ = timed(sweep_steps)
         sweep_rate = rays_per_step * sweep_steps / sweep_elapsed
@@ -558,8 +593,9 @@ def run_ranks(args):
                       "kernel": "grouped exhaustive sweep (R1_VARIANT_PREFILTER): every ray tested against every sphere group, "
                                 "as the reference's Hitable::hit does; same pixels; pixels + count on the host like `value`"}
         p = p_main
-        slots[0].step()  # leave launch_info / images describing the main kernel
-        torch.cuda.synchronize()
+        for _ in range(B):
+            slots[0].step()  # leave launch_info / images describing the main kernel
+        fence()
         info = rend.launch_info()
 
     # ---- what the timed kernel executes (measured, outside the timed region): one synchronous frame
@@ -576,7 +612,7 @@ def run_ranks(args):
         kernel_name = {1: "reference-form exhaustive sweep", 2: "grouped exhaustive sweep" + (" (LDS-tiled)" if info["spheres_active"] > 1023 else ""),
                        3: "grouped exhaustive sweep + counters", 4: "box tree (R1_VARIANT_BVH)", 5: "box tree + counters",
                        6: "wavefront: generate / intersect / shade kernels, box tree (comparison build)"}[info["kernel"]]
-        kernel_s = trace_ms_sum / max(frames, 1) * 1e-3  # average launch duration, HIP events on the stream of each launch
+        kernel_s = trace_ms_sum / max(launches, 1) * 1e-3  # average launch duration, HIP events on the stream of each launch
         overlap = trace_ms_sum * 1e-3 / elapsed           # launches of different frames overlap (frames in flight)
         traffic, traffic_source, valu_instr, valu_source, valu_lanes, valu_busy = None, None, None, None, None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -592,8 +628,9 @@ def run_ranks(args):
                     valu_source = f"{tj.get('valu_source', 'profiles/')} (not measured by this run)"
             except Exception:
                 traffic = None
-        flop = work.get("flop_per_launch") if work else None
-        agg = (flop * frames / elapsed / 1e12) if flop else None
+        flop_frame = work.get("flop_per_launch") if work else None  # measured on one synchronous frame = one frame's work
+        flop = flop_frame * frames / max(launches, 1) if flop_frame else None  # per launch of the timed region (a batch of frames)
+        agg = (flop_frame * frames / elapsed / 1e12) if flop_frame else None
         roofline = {
             # No dense contraction on this path (no MFMA) and the tables are cache resident, so neither of
             # the contract's two roofs binds: the roof is fp32 VECTOR issue.  `achieved` counts the flop the
@@ -606,7 +643,7 @@ def run_ranks(args):
             "frac": (agg / FP32_VECTOR_PEAK_TF) if agg else None,
             "traffic": traffic, "traffic_source": traffic_source,
             "kernel": "r1_trace_kernel" if info["kernel"] != 6 else "r1_wf_generate + 51 x (r1_wf_intersect, r1_wf_shade)",
-            "flop_per_launch": flop,
+            "flop_per_frame": flop_frame, "flop_per_launch": flop, "frames_per_launch": frames / max(launches, 1),
             "work": work,
             "launch_overlap": overlap,
             "per_launch": {"kernel_ms": kernel_s * 1e3,  # HIP events around each launch, on its stream; rocprofv3's average agrees (profiles/)
@@ -635,12 +672,14 @@ def run_ranks(args):
         host_mb = (img_bytes + 8) / 1e6 if not (sharded and n == 1) else record_bytes / 1e6
         cfg.update({
             "parallelism": f"tile-split x{n}" + (" + one RCCL all-gather per frame (pixels + ray counts)" if n > 1 else ""),
-            "value_mode": (f"{len(slots)} frames in flight (one stream + context each), scene resident in HBM; every frame ends with its "
-                           f"pixels + ray count copied to page-locked HOST memory ({host_mb:.2f} MB per frame) on its own stream, and the timed "
-                           "region ends when all copies have landed (rayweek1.cpp:848 -> :891, pipelined)") if host_copy[0] else
-                          f"{len(slots)} frames in flight (one stream + context each), scene and image resident in HBM",
+            "value_mode": (f"{len(slots) * B} frames in flight = {len(slots)} launches (one stream + context each) x {B} frames per launch, "
+                           f"scene resident in HBM; every frame ends with its pixels + ray count copied to page-locked HOST memory "
+                           f"({host_mb:.2f} MB per frame) on its launch's stream, and the timed region ends when all copies have landed "
+                           "(rayweek1.cpp:848 -> :891, pipelined)") if host_copy[0] else
+                          f"{len(slots) * B} frames in flight ({len(slots)} launches x {B} frames), scene and images resident in HBM",
             "workgroups": info["blocks"], "threads_per_workgroup": info["threads_per_block"],
-            "frames_in_flight": len(slots), "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+            "frames_in_flight": len(slots) * B, "launches_in_flight": len(slots), "frames_per_launch": B,
+            "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
             "host_submit_ms_per_step": submit / args.steps * 1e3,
             "kernel": kernel_name})
         if is_tree:

@@ -183,6 +183,19 @@ int r1_render_samples(r1_context *ctx, const r1_params *params, uint8_t *rgb_out
  * NULL: the frame is rendered and left in the context's device buffers (a measurement aid: what the copies cost). */
 int r1_render_async(r1_context *ctx, const r1_params *params, uint8_t *rgb_out, uint64_t *num_rays_out, void *hip_stream);
 
+/* Frame BATCHES: n_frames frames of the same scene, camera and size in ONE launch; frame f is seeded
+ * params->seed + f * seed_stride (0: identical frames; 1: the passes of a progressive render).  The trace kernel is
+ * persistent — a wave keeps refilling its lanes from a queue of samples — and what a launch costs beyond its samples is
+ * its ramp and, above all, its drain: the last ~40 iterations of every wave run with few live lanes.  In a batch the
+ * queue is frame-major and the waves flow from one frame into the next, so that cost is paid once per batch instead of
+ * once per frame (measured: DESIGN.md §4.9).  The price is latency: all frames of a batch are delivered together.
+ * host_frames receives n_frames frame records of r1_frame_record_bytes() each — the row-major image (as r1_render),
+ * padded to a multiple of 8 bytes, then the frame's uint64 ray count — with ONE copy enqueued behind the launch; nothing
+ * is waited for (as r1_render_async; page-locked memory recommended; NULL leaves the frames on the device).  Whole
+ * frames only.  Each frame's pixels and count equal what r1_render returns for its seed. */
+size_t r1_frame_record_bytes(const r1_params *params);
+int r1_render_batch_async(r1_context *ctx, const r1_params *params, int32_t n_frames, uint32_t seed_stride, void *host_frames, void *hip_stream);
+
 /* Page-locked host memory for r1_render_async's outputs (hipHostMalloc / hipHostFree). */
 int r1_host_alloc(size_t bytes, void **out);
 void r1_host_free(void *p);
@@ -206,6 +219,11 @@ size_t r1_shard_record_bytes(const r1_params *params);
  * Does not synchronise.  Sized for throughput: meant to be called for several frames in
  * flight (one context + stream per frame in flight). */
 int r1_render_shard_device(r1_context *ctx, const r1_params *params, void *d_block, void *d_num_rays, void *hip_stream);
+
+/* A batch of n_frames frames of this shard in one launch (see r1_render_batch_async): d_records receives n_frames
+ * records of r1_shard_record_bytes() each (dense tile block, padded to 8 bytes, + the shard's uint64 ray count of that
+ * frame), 8-byte aligned device memory — what a rank hands to ONE all-gather per batch. */
+int r1_render_shard_device_batch(r1_context *ctx, const r1_params *params, int32_t n_frames, uint32_t seed_stride, void *d_records, void *hip_stream);
 
 /* PIXEL mode for r1_render_shard_device (off by default).  On: a lane of the trace kernel owns a pixel and runs
  * its spp samples one after the other, so the `col += color()` of rayweek1.cpp:762 happens in a register in the
@@ -235,6 +253,11 @@ int r1_assemble_device_strided(r1_context *ctx, const r1_params *params, const v
  * *d_total_rays (device memory, 8-byte aligned; e.g. right behind the image, so that one copy brings both home). */
 int r1_assemble_device_records(r1_context *ctx, const r1_params *params, const void *d_records, void *d_rgb, void *d_total_rays,
                                void *hip_stream);
+
+/* Batches: d_gathered = the result of ONE all-gather of every shard's n_frames records, [shard][frame][record];
+ * d_frames receives n_frames frame records (r1_frame_record_bytes each: image + summed ray count). */
+int r1_assemble_device_records_batch(r1_context *ctx, const r1_params *params, int32_t n_frames, const void *d_gathered, void *d_frames,
+                                     void *hip_stream);
 
 /* Blocks until the context's stream is idle. */
 int r1_sync(r1_context *ctx);

@@ -100,6 +100,10 @@ SYMBOLS = [
     ("r1_shard_block_bytes", C.c_size_t, [C.POINTER(Params)]),
     ("r1_shard_record_bytes", C.c_size_t, [C.POINTER(Params)]),
     ("r1_render_async", C.c_int, [_ctx, C.POINTER(Params), _u8p, _u64p, C.c_void_p]),
+    ("r1_frame_record_bytes", C.c_size_t, [C.POINTER(Params)]),
+    ("r1_render_batch_async", C.c_int, [_ctx, C.POINTER(Params), C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    ("r1_render_shard_device_batch", C.c_int, [_ctx, C.POINTER(Params), C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    ("r1_assemble_device_records_batch", C.c_int, [_ctx, C.POINTER(Params), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("r1_host_alloc", C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     ("r1_host_free", None, [C.c_void_p]),
     ("r1_render_shard_device", C.c_int, [_ctx, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -252,6 +256,20 @@ class Renderer:
         _check(lib().r1_render_async(self._c, C.byref(params), C.cast(host_frame.ptr, _u8p),
                                      C.cast(host_frame.ptr + host_frame.rays_offset, _u64p), C.c_void_p(stream_ptr) if stream_ptr else None))
 
+    def render_batch_async(self, params, n_frames, host_frames, seed_stride=0, stream_ptr=None):
+        """r1_render_batch_async: n_frames frames in one launch; their records land in `host_frames` (a HostFrames, or None
+        to leave them on the device) once the stream is idle."""
+        _check(lib().r1_render_batch_async(self._c, C.byref(params), n_frames, seed_stride, C.c_void_p(host_frames.ptr) if host_frames else None,
+                                           C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def render_shard_device_batch(self, params, n_frames, d_records_ptr, seed_stride=0, stream_ptr=None):
+        _check(lib().r1_render_shard_device_batch(self._c, C.byref(params), n_frames, seed_stride, C.c_void_p(d_records_ptr),
+                                                  C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def assemble_device_records_batch(self, params, n_frames, d_gathered_ptr, d_frames_ptr, stream_ptr=None):
+        _check(lib().r1_assemble_device_records_batch(self._c, C.byref(params), n_frames, C.c_void_p(d_gathered_ptr), C.c_void_p(d_frames_ptr),
+                                                      C.c_void_p(stream_ptr) if stream_ptr else None))
+
     def render_frame_device(self, params, stream_ptr=None):
         """r1_render_async without host buffers: the frame stays in the context's device buffers (what the copies cost)."""
         _check(lib().r1_render_async(self._c, C.byref(params), None, None, C.c_void_p(stream_ptr) if stream_ptr else None))
@@ -362,6 +380,41 @@ class HostFrame:
             pass
 
 
+class HostFrames:
+    """Page-locked host memory for the n frame records of a batch (include/rays1.h r1_frame_record_bytes: image, padded
+    to 8 bytes, + uint64 ray count) — the target of Renderer.render_batch_async and of bench.py's copies."""
+
+    def __init__(self, width, height, n):
+        self.n, self.nbytes = n, width * height * 3
+        self.record = ((self.nbytes + 7) & ~7) + 8
+        p = C.c_void_p()
+        _check(lib().r1_host_alloc(self.record * n, C.byref(p)))
+        self.ptr = p.value
+        buf = (C.c_uint8 * (self.record * n)).from_address(self.ptr)
+        self._all = np.frombuffer(buf, np.uint8)
+        self._all[:] = 0
+        self._shape = (height, width, 3)
+        self.rays_offset = self.record - 8  # (a one-frame HostFrames is also a valid target of Renderer.render_async)
+
+    def image(self, i):
+        return self._all[i * self.record:i * self.record + self.nbytes].reshape(self._shape)
+
+    def rays(self, i):
+        return int(self._all[(i + 1) * self.record - 8:(i + 1) * self.record].view(np.uint64)[0])
+
+    def close(self):
+        if self.ptr:
+            self._all = None
+            lib().r1_host_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class MultiRenderer:
     """r1_multi: one process, N GPUs, tile split + one RCCL all-gather per frame (include/rays1.h)."""
 
@@ -403,6 +456,10 @@ class MultiRenderer:
 
 def shard_block_bytes(params):
     return int(lib().r1_shard_block_bytes(C.byref(params)))
+
+
+def frame_record_bytes(params):
+    return int(lib().r1_frame_record_bytes(C.byref(params)))
 
 
 def shard_record_bytes(params):

@@ -25,9 +25,10 @@ extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int 
 extern "C" int r1_trace_mode(int variant, int big, int wanted); // 0 samples + one queue, 1 latency, 2 pixel: what is built for (variant, big)
 extern "C" hipError_t r1_launch_resolve(const R1ResolveArgs *args, hipStream_t stream);
 extern "C" hipError_t r1_launch_wavefront(R1WaveArgs *w, int blocks, hipStream_t stream);
-extern "C" hipError_t r1_launch_assemble(const void *blocks, void *rgb, int width, int height, int tile_w, int tile_h, int tiles_x,
-                                         int tiles_total, int num_shards, int tiles_per_shard, size_t shard_stride, void *total_rays,
-                                         hipStream_t stream);
+extern "C" hipError_t r1_launch_assemble(const void *blocks, void *rgb, int width, int height, int tile_w, int tile_h, int tiles_x, int num_shards,
+                                         size_t shard_stride, int n_frames, size_t frame_in, size_t frame_out, size_t total_offset, long long total_out,
+                                         int want_total, hipStream_t stream);
+extern "C" size_t r1_frame_record_bytes(const r1_params *p); // r1_host.cpp
 extern "C" hipError_t r1_trace_occupancy(int variant, int big, int mode, size_t dyn_lds, int *blocks_per_cu);
 extern "C" int r1_params_check(const r1_params *p); // r1_host.cpp
 
@@ -117,6 +118,9 @@ struct r1_context
 
     // per-frame workspace
     DevBuf counters, samples, image;
+    R1BatchArgs batch_args_host = {0, 0, {0, 0, 0}, 0}; // what the device copy (counters + R1_COUNTER_BYTES + 16) holds
+    DevBuf batch_rays;  // frame batches: per-frame ray-count accumulators of the resolve launch + its finished-workgroup counter
+    int tile_frames = 0; // frames per launch the tile arithmetic below was made for
     bool counters_clean = false; // the last frame's resolve launch zeroed the counter block: the next frame needs no memset
     r1_params tile_key;
     bool tile_key_valid = false;
@@ -221,7 +225,7 @@ extern "C" void r1_destroy(r1_context *c)
     release(c->sweep), release(c->exact), release(c->shade), release(c->mat), release(c->members);
     release(c->bvh_nodes), release(c->bvh_prims), release(c->bvh_ids);
     release(c->wf_paths), release(c->wf_hits), release(c->wf_queue), release(c->wf_counts);
-    release(c->gstack), release(c->counters), release(c->samples), release(c->image);
+    release(c->gstack), release(c->counters), release(c->samples), release(c->image), release(c->batch_rays);
     release(c->wave_log);
     for (hipEvent_t e : c->ring)
         (void)hipEventDestroy(e);
@@ -587,32 +591,44 @@ static R1FastDiv make_div(uint32_t d)
     return r;
 }
 
-static int prepare_tiles(r1_context *c, const r1_params *p)
+static int prepare_tiles(r1_context *c, const r1_params *p, int n_frames)
 {
-    if (c->tile_key_valid && same_tiling(c->tile_key, *p))
+    if (c->tile_key_valid && same_tiling(c->tile_key, *p) && c->tile_frames == n_frames)
         return R1_OK;
     const int tiles_x = (p->width + p->tile_w - 1) / p->tile_w;
     const int tiles_y = (p->height + p->tile_h - 1) / p->tile_h;
     const int total = tiles_x * tiles_y;
     const uint32_t local = total > p->shard ? (uint32_t)((total - p->shard + p->num_shards - 1) / p->num_shards) : 0u;
     const uint64_t full = (uint64_t)p->tile_w * p->tile_h * p->spp;
-    if (full * local >= ((uint64_t)1 << 31) || (uint64_t)total * p->num_shards >= ((uint64_t)1 << 31))
+    if (full * local * (uint64_t)n_frames >= ((uint64_t)1 << 31) || (uint64_t)total * p->num_shards >= ((uint64_t)1 << 31))
     {
-        r1_set_error("frame %dx%dx%d with %dx%d tiles exceeds 2^31 sample slots per device", p->width, p->height, p->spp, p->tile_w, p->tile_h);
+        r1_set_error("%d frame(s) of %dx%dx%d with %dx%d tiles exceed 2^31 sample slots per launch", n_frames, p->width, p->height, p->spp, p->tile_w,
+                     p->tile_h);
         return R1_ELIMIT;
     }
     c->n_local_tiles = local;
     c->full = (uint32_t)full;
-    c->total_samples = (uint32_t)(full * local);
+    c->total_samples = (uint32_t)(full * local * (uint64_t)n_frames); // the launch's queue: frame-major
     c->tile_key = *p;
+    c->tile_frames = n_frames;
     c->tile_key_valid = true;
     return R1_OK;
 }
 
+// Frame batch of the throughput entry points: n_frames frames in one launch (r1_device.h R1TraceArgs::n_frames); frame f is
+// written to d_out + f * out_stride and its uint64 ray count to d_out + f * out_stride + rays_offset.
+struct Batch
+{
+    int n_frames = 1;
+    uint32_t seed_stride = 0;
+    size_t out_stride = 0, rays_offset = 0;
+};
+
 // Enqueues trace + resolve on `st`. out/d_rays are device pointers.
 static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int block_layout, void *d_rays, hipStream_t st,
-                         bool throughput_mode)
+                         bool throughput_mode, const Batch *batch = nullptr)
 {
+    const int n_frames = batch ? batch->n_frames : 1;
     if (!c->have_scene)
     {
         r1_set_error("no scene set (call r1_set_scene first)");
@@ -638,7 +654,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     default: variant = 2; break;
     }
     R1_HIP(hipSetDevice(c->device));
-    if ((rc = prepare_tiles(c, p)))
+    if ((rc = prepare_tiles(c, p, n_frames)))
         return rc;
     if ((rc = ensure(c->counters, R1_COUNTER_BYTES + 64)))
         return rc;
@@ -651,6 +667,18 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     const int tp_mode = c->pixel_mode ? 2 : (tp_mode_env >= 0 && tp_mode_env <= 2 ? tp_mode_env : 0);
     const int mode = variant == 6 ? 0 : r1_trace_mode(variant, big_scene_, throughput_mode ? tp_mode : 1);
     const bool pixel_mode = mode == 2;
+    if (batch && (mode != 0 || variant == 6 || variant == 3 || variant == 5 || variant == 1))
+    {
+        r1_set_error("frame batches run through the throughput kernels only (no PIXEL mode, no diagnostic / reference-form / wavefront variant)");
+        return R1_EINVAL;
+    }
+    if (batch)
+    {
+        // partial ray counts of the resolve launch: one uint64 per (tile of the batch, workgroup column)
+        const size_t cols = ((size_t)p->tile_w * p->tile_h + 255) / 256;
+        if ((rc = ensure(c->batch_rays, (size_t)n_frames * (c->n_local_tiles ? c->n_local_tiles : 1) * cols * 8)))
+            return rc;
+    }
     if (!pixel_mode && (rc = ensure(c->samples, (size_t)(c->total_samples ? c->total_samples : 1) * 16)))
         return rc;
 
@@ -679,6 +707,21 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     a.tiles_x = (p->width + p->tile_w - 1) / p->tile_w;
     a.shard = p->shard, a.num_shards = p->num_shards;
     a.n_local_tiles = c->n_local_tiles;
+    a.batch = nullptr;
+    if (batch && n_frames > 1)
+    {
+        // the batch's numbers, in the context's counter allocation behind the published ray count (stream-ordered upload:
+        // the previous launch through this context has finished reading its copy by the time this one is written)
+        R1BatchArgs ba;
+        ba.n_frames = (uint32_t)n_frames, ba.seed_stride = batch->seed_stride;
+        ba.div_tiles = make_div(c->n_local_tiles ? c->n_local_tiles : 1u), ba.n_local_tiles = c->n_local_tiles;
+        if (memcmp(&ba, &c->batch_args_host, sizeof(ba)) != 0)
+        {
+            c->batch_args_host = ba;
+            R1_HIP(hipMemcpyAsync((char *)c->counters.p + R1_COUNTER_BYTES + 16, &c->batch_args_host, sizeof(ba), hipMemcpyHostToDevice, st));
+        }
+        a.batch = (const R1BatchArgs *)((char *)c->counters.p + R1_COUNTER_BYTES + 16);
+    }
     a.full = c->full;
     a.div_full = make_div(c->full);
     a.div_spp = make_div((uint32_t)p->spp);
@@ -871,6 +914,12 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     r.inv_spp = (float)(1.0f / p->spp); // rayweek1.cpp:765
     r.out = (uint8_t *)d_out;
     r.block_layout = block_layout;
+    r.n_frames = (uint32_t)n_frames;
+    if (batch)
+    {
+        r.out_stride = batch->out_stride, r.rays_offset = batch->rays_offset;
+        r.frame_rays = (unsigned long long *)c->batch_rays.p;
+    }
     if (fused_clear)
     {
         r.rays_src = (const unsigned long long *)((char *)c->counters.p + 32);
@@ -879,6 +928,9 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     }
     if (c->n_local_tiles && !pixel_mode)
         R1_HIP(r1_launch_resolve(&r, st));
+    else if (batch) // a shard without tiles: its frames' counts are zero
+        for (int f = 0; f < n_frames; ++f)
+            R1_HIP(hipMemsetAsync((char *)d_out + (size_t)f * batch->out_stride + batch->rays_offset, 0, 8, st));
     c->counters_clean = fused_clear;
     R1_HIP(hipEventRecord(e2, st));
     c->last0 = e0, c->last1 = e1, c->last2 = e2;
@@ -1039,6 +1091,61 @@ extern "C" int r1_render_async(r1_context *c, const r1_params *p, uint8_t *rgb_o
     return R1_OK;
 }
 
+// n_frames frames of the same scene, camera and size in ONE launch (frame f seeded params->seed + f * seed_stride): the
+// persistent waves flow from one frame into the next, so the ramp and drain of a launch are paid once per batch.
+// Whole frames (num_shards == 1): host_frames receives n_frames frame records (r1_frame_record_bytes each) with ONE copy.
+extern "C" int r1_render_batch_async(r1_context *c, const r1_params *p, int32_t n_frames, uint32_t seed_stride, void *host_frames, void *hip_stream)
+{
+    if (!c || !p || n_frames < 1)
+    {
+        r1_set_error("r1_render_batch_async: bad argument");
+        return R1_EINVAL;
+    }
+    int rc = r1_params_check(p);
+    if (rc)
+        return rc;
+    if (p->num_shards != 1)
+    {
+        r1_set_error("r1_render_batch_async renders whole frames (num_shards == 1); shards go through r1_render_shard_device_batch");
+        return R1_EINVAL;
+    }
+    R1_HIP(hipSetDevice(c->device));
+    const size_t frame = r1_frame_record_bytes(p);
+    if ((rc = ensure(c->image, frame * (size_t)n_frames)))
+        return rc;
+    if ((rc = ensure(c->counters, R1_COUNTER_BYTES + 64)))
+        return rc;
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    Batch b;
+    b.n_frames = n_frames, b.seed_stride = seed_stride, b.out_stride = frame, b.rays_offset = frame - 8;
+    if ((rc = enqueue_frame(c, p, c->image.p, 0, (char *)c->counters.p + R1_COUNTER_BYTES, st, true, &b)))
+        return rc;
+    if (host_frames) // (NULL: the frames stay in the context's device buffer — a measurement aid)
+        R1_HIP(hipMemcpyAsync(host_frames, c->image.p, frame * (size_t)n_frames, hipMemcpyDeviceToHost, st));
+    return R1_OK;
+}
+
+// The same for one shard of n_frames frames: d_records receives n_frames records (r1_shard_record_bytes each: dense tile
+// block + uint64 ray count), device memory — what a rank hands to ONE all-gather per batch.
+extern "C" int r1_render_shard_device_batch(r1_context *c, const r1_params *p, int32_t n_frames, uint32_t seed_stride, void *d_records, void *hip_stream)
+{
+    if (!c || !p || !d_records || n_frames < 1 || ((uintptr_t)d_records & 7u))
+    {
+        r1_set_error("r1_render_shard_device_batch: bad argument (d_records must be 8-byte aligned)");
+        return R1_EINVAL;
+    }
+    int rc = r1_params_check(p);
+    if (rc)
+        return rc;
+    if ((rc = ensure(c->counters, R1_COUNTER_BYTES + 64)))
+        return rc;
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    const size_t record = r1_shard_record_bytes(p);
+    Batch b;
+    b.n_frames = n_frames, b.seed_stride = seed_stride, b.out_stride = record, b.rays_offset = record - 8;
+    return enqueue_frame(c, p, d_records, 1, (char *)c->counters.p + R1_COUNTER_BYTES, st, true, &b);
+}
+
 extern "C" int r1_host_alloc(size_t bytes, void **out)
 {
     if (!out || bytes == 0)
@@ -1089,7 +1196,7 @@ extern "C" int r1_render_shard_device_once(r1_context *c, const r1_params *p, vo
 }
 
 static int assemble_common(r1_context *c, const r1_params *p, const void *d_blocks, size_t shard_stride_bytes, void *d_rgb, void *d_total_rays,
-                           void *hip_stream)
+                           void *hip_stream, int n_frames = 1, size_t frame_in = 0, size_t frame_out = 0)
 {
     if (!c || !p || !d_blocks || !d_rgb)
     {
@@ -1108,16 +1215,17 @@ static int assemble_common(r1_context *c, const r1_params *p, const void *d_bloc
         r1_set_error("r1_assemble_device: shard stride %zu smaller than a shard block (%zu bytes)", shard_stride_bytes, tight);
         return R1_EINVAL;
     }
-    if (d_total_rays && (((uintptr_t)d_total_rays | (uintptr_t)d_blocks | shard_stride_bytes) & 7u))
+    if (d_total_rays && (((uintptr_t)d_total_rays | (uintptr_t)d_blocks | shard_stride_bytes | frame_in | frame_out) & 7u))
     {
-        r1_set_error("r1_assemble_device_records: records and the total must be 8-byte aligned");
+        r1_set_error("r1_assemble_device_records: records and totals must be 8-byte aligned");
         return R1_EINVAL;
     }
     R1_HIP(hipSetDevice(c->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     const int tiles_x = (p->width + p->tile_w - 1) / p->tile_w;
-    R1_HIP(r1_launch_assemble(d_blocks, d_rgb, p->width, p->height, p->tile_w, p->tile_h, tiles_x, total, p->num_shards, per,
-                              shard_stride_bytes, d_total_rays, st));
+    const size_t record = r1_shard_record_bytes(p);
+    R1_HIP(r1_launch_assemble(d_blocks, d_rgb, p->width, p->height, p->tile_w, p->tile_h, tiles_x, p->num_shards, shard_stride_bytes, n_frames, frame_in,
+                              frame_out, record - 8, d_total_rays ? (long long)((char *)d_total_rays - (char *)d_rgb) : 0, d_total_rays ? 1 : 0, st));
     return R1_OK;
 }
 
@@ -1135,6 +1243,22 @@ extern "C" int r1_assemble_device_records(r1_context *c, const r1_params *p, con
         return R1_EINVAL;
     }
     return assemble_common(c, p, d_records, r1_shard_record_bytes(p), d_rgb, d_total_rays, hip_stream);
+}
+
+// Batches: d_gathered = what one all-gather of every shard's n_frames records returns, [shard][frame][record]; d_frames receives
+// n_frames frame records (r1_frame_record_bytes each: row-major image, padded to 8 bytes, + the frame's uint64 ray count).
+extern "C" int r1_assemble_device_records_batch(r1_context *c, const r1_params *p, int32_t n_frames, const void *d_gathered, void *d_frames,
+                                                void *hip_stream)
+{
+    if (n_frames < 1 || !d_frames)
+    {
+        r1_set_error("r1_assemble_device_records_batch: bad argument");
+        return R1_EINVAL;
+    }
+    const size_t record = r1_shard_record_bytes(p), frame = r1_frame_record_bytes(p);
+    if (!record)
+        return R1_EINVAL;
+    return assemble_common(c, p, d_gathered, record * (size_t)n_frames, d_frames, (char *)d_frames + frame - 8, hip_stream, n_frames, record, frame);
 }
 
 extern "C" int r1_assemble_device(r1_context *c, const r1_params *p, const void *d_blocks, void *d_rgb, void *hip_stream)

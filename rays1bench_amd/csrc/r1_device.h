@@ -72,6 +72,15 @@ struct R1FastDiv
     uint32_t mul, shift, pow2;
 };
 
+// Frame batches (R1TraceArgs::batch), device memory
+struct R1BatchArgs
+{
+    uint32_t n_frames;   // >= 2
+    uint32_t seed_stride;
+    R1FastDiv div_tiles; // by n_local_tiles
+    uint32_t n_local_tiles;
+};
+
 // Everything the trace kernel needs; passed by value (kernarg segment => SGPRs).
 struct R1DeviceScene
 {
@@ -117,7 +126,14 @@ struct R1TraceArgs
     float inv_w, inv_h;          // 1.0f / width, 1.0f / height (IEEE divisions done on the host)
     int32_t tile_w, tile_h, tiles_x;
     int32_t shard, num_shards;
-    uint32_t n_local_tiles;      // tiles this shard owns
+    uint32_t n_local_tiles;      // tiles this shard owns (per frame)
+    // Frame batches (throughput entry points): ONE launch carries n_frames frames of the same scene, camera and size.  The
+    // queue is frame-major — padded tile index j = f * n_local_tiles + (local tile of frame f) — so the persistent waves flow
+    // from one frame into the next without draining (a wave's last ~40 iterations run with few live lanes; per frame of
+    // 1200x800x10 that is ~8 % of its iterations, per 1/8-frame of an 8-GPU rank ~25 %).  Frame f is seeded seed + f * seed_stride.
+    // The batch's numbers sit behind a pointer (null: a single frame) and are fetched with scalar loads where a sample starts:
+    // five more kernel arguments cost the tree kernel nine more spilled SGPRs and 2 % of its rate.
+    const struct R1BatchArgs *batch;
     // Sample slots are enumerated over PADDED tiles: slot k = (local tile j, pixel in the
     // tile_w x tile_h tile, sample s) = ((j * tile_h + ly) * tile_w + lx) * spp + s.  Slots of
     // pixels outside the image (right/top edge tiles) are void: skipped by the tracer, never
@@ -167,10 +183,17 @@ struct R1ResolveArgs
     int32_t width, height, spp;
     int32_t tile_w, tile_h, tiles_x;
     int32_t shard, num_shards;
-    uint32_t n_local_tiles;
+    uint32_t n_local_tiles;      // per frame
     float inv_spp;               // (float)(1.0f / spp)
-    uint8_t *out;                // row-major image or dense tile block
+    uint8_t *out;                // row-major image or dense tile block (of frame 0)
     int32_t block_layout;        // 0: row-major width*height*3, 1: dense tile block
+    // frame batches: frame f resolves tiles [f * n_local_tiles, (f + 1) * n_local_tiles) of the sample records into
+    // out + f * out_stride; its ray count — the sum of its samples' counts, rayweek1.cpp:809-813 — is left as partial sums
+    // in frame_rays[(tile of the batch) * gridDim.x + blockIdx.x] (plain stores, no atomics) and added up per frame by
+    // r1_batch_counts_kernel into out + f * out_stride + rays_offset (uint64)
+    uint32_t n_frames;
+    size_t out_stride, rays_offset;
+    unsigned long long *frame_rays; // null: single frame, the trace kernel counted
     // end of the frame (block (0,0), after the trace kernel): publish the ray count the trace kernel accumulated in the
     // context's counter block, then zero the block for the next frame — two memset launches per frame less
     const unsigned long long *rays_src; // null: the trace kernel counted into the caller's word itself

@@ -311,6 +311,15 @@ extern "C" size_t r1_shard_record_bytes(const r1_params *p)
     return block ? ((block + 7u) & ~(size_t)7u) + 8u : 0u;
 }
 
+// One whole frame as the batch entry points deliver it: the row-major image, padded to a multiple of 8 bytes, then the
+// frame's uint64 ray count.
+extern "C" size_t r1_frame_record_bytes(const r1_params *p)
+{
+    if (r1_params_check(p))
+        return 0;
+    return (((size_t)p->width * p->height * 3 + 7u) & ~(size_t)7u) + 8u;
+}
+
 // ---- output formats (src/common/common.h) ---------------------------------------------
 
 extern "C" int r1_tga_write_rgb24(const char *filename, int32_t width, int32_t height, uint8_t *pixels)

@@ -890,9 +890,9 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t n, const R1FastDiv dv)
 }
 
 // seeds + primary ray of sample s of pixel (x, y) (rayweek1.cpp:759-760)
-__device__ __forceinline__ void start_ray(const R1TraceArgs &A, Path &p, const int x, const int y, const uint32_t s)
+__device__ __forceinline__ void start_ray(const R1TraceArgs &A, Path &p, const int x, const int y, const uint32_t s, const uint32_t seed)
 {
-    const r1_sample_seed sd = r1_seed_sample(A.seed, (uint32_t)(y * A.width + x), s);
+    const r1_sample_seed sd = r1_seed_sample(seed, (uint32_t)(y * A.width + x), s);
     p.s_scalar = sd.scalar;
     p.s0 = sd.lane0;
     p.s1 = sd.lane1;
@@ -941,19 +941,31 @@ __device__ __forceinline__ bool tile_pixel(const R1TraceArgs &A, const uint32_t 
 
 // sample slot k -> (tile, pixel, sample); then seeds + primary ray.
 // Returns false for a void slot (pixel of an edge tile that lies outside the image).
+template <bool BATCH = false>
 __device__ __forceinline__ bool start_sample(const R1TraceArgs &A, Path &p, uint32_t k)
 {
-    const uint32_t j = fastdiv(k, A.div_full);
+    const uint32_t j = fastdiv(k, A.div_full); // padded tile, frame-major over the frames of the launch
     const uint32_t r = k - j * A.full;
     const uint32_t pix = fastdiv(r, A.div_spp);
     const uint32_t s = r - pix * (uint32_t)A.spp;
+    uint32_t jl = j, seed = A.seed;
+    if (BATCH) // (its own build of the kernel, MODE 3: the single-frame kernels stay as they were, to the register)
+    {
+        typedef const uint32_t __attribute__((address_space(4))) *cu32_ptr;
+        const cu32_ptr b = (cu32_ptr)A.batch; // {n_frames, seed_stride, div_tiles{mul, shift, pow2}, n_local_tiles}
+        R1FastDiv dv;
+        dv.mul = b[2], dv.shift = b[3], dv.pow2 = b[4];
+        const uint32_t f = fastdiv(j, dv);
+        jl = j - f * b[5];
+        seed += f * b[1];
+    }
     int x, y;
-    if (!tile_pixel(A, j, pix, x, y))
+    if (!tile_pixel(A, jl, pix, x, y))
         return false;
     // output slot: samples are stored [tile][sample][pixel] so that the resolve pass reads
     // coalesced (consecutive pixels of one sample index)
     p.k = (j * (uint32_t)A.spp + s) * (uint32_t)(A.tile_w * A.tile_h) + pix;
-    start_ray(A, p, x, y, s);
+    start_ray(A, p, x, y, s, seed);
     return true;
 }
 
@@ -1183,7 +1195,7 @@ struct TraceWaves
 template <int VARIANT, bool STATS, bool BIG, int MODE>
 __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::value)) r1_trace_kernel(const R1TraceArgs A)
 {
-    constexpr bool LAT = MODE == 1, PIX = MODE == 2;
+    constexpr bool LAT = MODE == 1, PIX = MODE == 2, BATCH = MODE == 3; // MODE 3 = MODE 0 whose queue spans the frames of a batch
     typedef typename IdxType<BIG>::type IDX;
     unsigned long long wstat[17];
     if (STATS)
@@ -1255,7 +1267,7 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
 #ifndef R1_SPARE_MIN
 #define R1_SPARE_MIN 40u
 #endif
-    constexpr bool SPARE = R1_SPARE && !BIG && (VARIANT == 4 || VARIANT == 2) && MODE == 0; // (big scenes: the registers buy an eighth wave instead)
+    constexpr bool SPARE = R1_SPARE && !BIG && (VARIANT == 4 || VARIANT == 2) && (MODE == 0 || MODE == 3); // (big scenes: the registers buy an eighth wave instead)
     Path spare = p;
     bool has_spare = false;
 
@@ -1280,7 +1292,7 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
         if (PIX && !alive && px.s < (uint32_t)A.spp)
         {
             // the next sample of the pixel in hand: no queue, no index arithmetic
-            start_ray(A, p, (int)(px.xy & 0xFFFFu), (int)(px.xy >> 16), px.s);
+            start_ray(A, p, (int)(px.xy & 0xFFFFu), (int)(px.xy >> 16), px.s, A.seed);
             alive = true;
             if (VARIANT == 4)
                 trav_start(tv);
@@ -1343,7 +1355,7 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
             if (SPARE)
             {
                 if (!has_spare && rank < avail)
-                    has_spare = start_sample(A, spare, q_next + rank); // false: void slot, ask again
+                    has_spare = start_sample<BATCH>(A, spare, q_next + rank); // false: void slot, ask again
             }
             else if (!alive && rank < avail)
             {
@@ -1351,10 +1363,10 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
                 {
                     alive = pixel_take(A, px, q_next + rank); // false: void slot, ask again
                     if (alive)
-                        start_ray(A, p, (int)(px.xy & 0xFFFFu), (int)(px.xy >> 16), 0u);
+                        start_ray(A, p, (int)(px.xy & 0xFFFFu), (int)(px.xy >> 16), 0u, A.seed);
                 }
                 else
-                    alive = start_sample(A, p, q_next + rank); // false: void slot, ask again
+                    alive = start_sample<BATCH>(A, p, q_next + rank); // false: void slot, ask again
                 if (VARIANT == 4 && alive)
                     trav_start(tv);
             }
@@ -1620,14 +1632,18 @@ __global__ void __launch_bounds__(256) r1_resolve_kernel(const R1ResolveArgs A)
             ((uint4 *)A.reset)[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
     }
     const uint32_t tiles_stride = gridDim.y;
-    for (uint32_t lt = blockIdx.y; lt < A.n_local_tiles; lt += tiles_stride)
+    const uint32_t tiles_all = A.n_local_tiles * (A.n_frames ? A.n_frames : 1u);
+    for (uint32_t lt_all = blockIdx.y; lt_all < tiles_all; lt_all += tiles_stride)
     {
+        const uint32_t f = lt_all / A.n_local_tiles, lt = lt_all - f * A.n_local_tiles; // frame of the batch, its local tile
+        uint8_t *const out = A.out + (size_t)f * A.out_stride;
         const uint32_t tile = (uint32_t)A.shard + lt * (uint32_t)A.num_shards;
         const int x0 = (int)(tile % (uint32_t)A.tiles_x) * A.tile_w;
         const int y0 = (int)(tile / (uint32_t)A.tiles_x) * A.tile_h;
         const int tw = min(A.tile_w, A.width - x0);
         const int th = min(A.tile_h, A.height - y0);
-        const uint32_t base = lt * A.full;
+        const uint32_t base = lt_all * A.full;
+        unsigned long long rays = 0;
         for (uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x; pix < (uint32_t)(A.tile_w * A.tile_h); pix += gridDim.x * blockDim.x)
         {
             const int ly = (int)(pix / (uint32_t)A.tile_w);
@@ -1641,6 +1657,7 @@ __global__ void __launch_bounds__(256) r1_resolve_kernel(const R1ResolveArgs A)
             {
                 const float4 v = s[(size_t)i * tile_px];
                 cr += v.x, cg += v.y, cb += v.z; // col += color(...) rayweek1.cpp:762
+                rays += __float_as_uint(v.w);
             }
             cr *= A.inv_spp, cg *= A.inv_spp, cb *= A.inv_spp;
             cr = ieee_sqrt(cr), cg = ieee_sqrt(cg), cb = ieee_sqrt(cb);
@@ -1652,26 +1669,66 @@ __global__ void __launch_bounds__(256) r1_resolve_kernel(const R1ResolveArgs A)
                 o = ((size_t)lt * A.tile_h * A.tile_w + (size_t)ly * A.tile_w + lx) * 3;
             else
                 o = ((size_t)(y0 + ly) * A.width + (x0 + lx)) * 3;
-            A.out[o + 0] = r;
-            A.out[o + 1] = g;
-            A.out[o + 2] = b;
+            out[o + 0] = r;
+            out[o + 1] = g;
+            out[o + 2] = b;
+        }
+        if (A.frame_rays) // frame batches: the frame's ray count is the sum over its samples (rayweek1.cpp:809-813)
+        {
+            // no atomics: 15 000 waves adding to one word per frame cost more than the whole resolve (a returning or
+            // non-returning atomic on ONE line sustains ~88 M/s on this chip, tools/ubench_atomic.hip).  Every workgroup
+            // stores ONE partial sum per tile it touches; r1_batch_counts_kernel adds them up per frame.
+            __shared__ unsigned long long s_part[4];
+            for (int off = 32; off > 0; off >>= 1)
+                rays += __shfl_down(rays, off, 64);
+            if ((threadIdx.x & 63u) == 0)
+                s_part[threadIdx.x >> 6] = rays;
+            __syncthreads();
+            if (threadIdx.x == 0)
+                A.frame_rays[(size_t)lt_all * gridDim.x + blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+            __syncthreads();
         }
     }
 }
 
-// Scatter gathered dense tile blocks (shard-major) into a row-major image.
+// Frame batches: frame f's ray count = the sum of the partial sums the resolve launch left per (tile, workgroup column);
+// one workgroup per frame; the count goes next to the frame's pixels (out + f * out_stride + rays_offset).
 __global__ void __launch_bounds__(256)
-    r1_assemble_kernel(const uint8_t *__restrict__ blocks, uint8_t *__restrict__ rgb, int width, int height, int tile_w, int tile_h,
-                       int tiles_x, int tiles_total, int num_shards, int tiles_per_shard, size_t shard_stride, unsigned long long *total_rays)
+    r1_batch_counts_kernel(const unsigned long long *__restrict__ partial, uint32_t per_frame, uint8_t *__restrict__ out, size_t out_stride,
+                           size_t rays_offset)
 {
-    // gathered RECORDS (block + uint64 count at the end of every stride): the frame's ray count is the sum of the
+    __shared__ unsigned long long s_part[4];
+    const unsigned long long *src = partial + (size_t)blockIdx.x * per_frame;
+    unsigned long long sum = 0;
+    for (uint32_t i = threadIdx.x; i < per_frame; i += blockDim.x)
+        sum += src[i];
+    for (int off = 32; off > 0; off >>= 1)
+        sum += __shfl_down(sum, off, 64);
+    if ((threadIdx.x & 63u) == 0)
+        s_part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        *(unsigned long long *)(out + (size_t)blockIdx.x * out_stride + rays_offset) = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+// Scatter gathered dense tile blocks (shard-major) into a row-major image.  Frame batches: blockIdx.y = frame; the
+// frame's blocks start frame_in bytes after `blocks` (gathered layout [shard][frame][record]) and its image frame_out
+// bytes after `rgb`.
+__global__ void __launch_bounds__(256)
+    r1_assemble_kernel(const uint8_t *__restrict__ blocks_all, uint8_t *__restrict__ rgb_all, int width, int height, int tile_w, int tile_h,
+                       int tiles_x, int num_shards, size_t shard_stride, size_t frame_in, size_t frame_out, size_t total_offset, long long total_out,
+                       int want_total)
+{
+    const uint8_t *__restrict__ blocks = blocks_all + (size_t)blockIdx.y * frame_in;
+    uint8_t *__restrict__ rgb = rgb_all + (size_t)blockIdx.y * frame_out;
+    // gathered RECORDS (block + uint64 count at the end of every record): the frame's ray count is the sum of the
     // shards' counts (rayweek1.cpp:809-813), written next to the image so that one copy brings both to the host
-    if (total_rays && blockIdx.x == 0 && threadIdx.x == 0)
+    if (want_total && blockIdx.x == 0 && threadIdx.x == 0)
     {
         unsigned long long sum = 0;
         for (int sh = 0; sh < num_shards; ++sh)
-            sum += *(const unsigned long long *)(blocks + (size_t)(sh + 1) * shard_stride - 8);
-        *total_rays = sum;
+            sum += *(const unsigned long long *)(blocks + (size_t)sh * shard_stride + total_offset);
+        *(unsigned long long *)(rgb + total_out) = sum;
     }
     const size_t n = (size_t)width * height;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -1684,8 +1741,6 @@ __global__ void __launch_bounds__(256)
         rgb[3 * i + 1] = blocks[src + 1];
         rgb[3 * i + 2] = blocks[src + 2];
     }
-    (void)tiles_total;
-    (void)tiles_per_shard;
 }
 
 // ---- launchers (called from r1_capi.cpp) -----------------------------------------------------
@@ -1712,6 +1767,9 @@ extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int 
 #define R1_GO(V, S, B, M) hipLaunchKernelGGL((r1_trace_kernel<V, S, B, M>), dim3(blocks), dim3(R1_BLOCK), (V) == 4 ? trav : 0, stream, *args)
     if (mode != r1_trace_mode(variant, big_in, mode))
         return hipErrorInvalidValue; // the caller sizes its arguments by the mode: it must be the one that is built
+    const bool batch = args->batch != nullptr; // frame batches: the MODE 3 build of the throughput kernels (variants 2 and 4 only)
+    if (batch && (mode != 0 || (variant != 2 && variant != 4)))
+        return hipErrorInvalidValue;
     if (variant == 5 && big)
         R1_GO(4, true, true, 0);
     else if (variant == 5)
@@ -1720,6 +1778,8 @@ extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int 
     {
         if (mode == 2)
             R1_GO(4, false, true, 2);
+        else if (batch)
+            R1_GO(4, false, true, 3);
         else
             R1_GO(4, false, true, 0);
     }
@@ -1729,6 +1789,8 @@ extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int 
             R1_GO(4, false, false, 2);
         else if (mode == 1)
             R1_GO(4, false, false, 1);
+        else if (batch)
+            R1_GO(4, false, false, 3);
         else
             R1_GO(4, false, false, 0);
     }
@@ -1742,6 +1804,8 @@ extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int 
     {
         if (mode == 2)
             R1_GO(2, false, true, 2);
+        else if (batch)
+            R1_GO(2, false, true, 3);
         else
             R1_GO(2, false, true, 0);
     }
@@ -1749,6 +1813,8 @@ extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int 
         R1_GO(2, false, false, 2);
     else if (mode == 1)
         R1_GO(2, false, false, 1);
+    else if (batch)
+        R1_GO(2, false, false, 3);
     else
         R1_GO(2, false, false, 0);
 #undef R1_GO
@@ -1773,21 +1839,28 @@ extern "C" hipError_t r1_launch_resolve(const R1ResolveArgs *args, hipStream_t s
 {
     const int tile_pix = args->tile_w * args->tile_h;
     const int bx = (tile_pix + 255) / 256;
-    const int by = (int)(args->n_local_tiles < 65535u ? args->n_local_tiles : 65535u);
+    const uint32_t tiles_all = args->n_local_tiles * (args->n_frames ? args->n_frames : 1u);
+    const int by = (int)(tiles_all < 65535u ? tiles_all : 65535u);
     hipLaunchKernelGGL(r1_resolve_kernel, dim3(bx, by), dim3(256), 0, stream, *args);
+    if (args->frame_rays) // frame batches: per-frame ray counts from the launch's partial sums ([tile of the batch][bx])
+        hipLaunchKernelGGL(r1_batch_counts_kernel, dim3(args->n_frames), dim3(256), 0, stream, args->frame_rays, args->n_local_tiles * (uint32_t)bx,
+                           args->out, args->out_stride, args->rays_offset);
     return hipGetLastError();
 }
 
-extern "C" hipError_t r1_launch_assemble(const void *blocks, void *rgb, int width, int height, int tile_w, int tile_h, int tiles_x,
-                                         int tiles_total, int num_shards, int tiles_per_shard, size_t shard_stride, void *total_rays,
-                                         hipStream_t stream)
+// blocks: gathered tile blocks or records; per frame f (0 .. n_frames - 1): shard sh's block at blocks + f * frame_in + sh * shard_stride,
+// image at rgb + f * frame_out.  want_total: the shards' uint64 counts at (block start + total_offset) are summed into the
+// uint64 at (the frame's image + total_out).
+extern "C" hipError_t r1_launch_assemble(const void *blocks, void *rgb, int width, int height, int tile_w, int tile_h, int tiles_x, int num_shards,
+                                         size_t shard_stride, int n_frames, size_t frame_in, size_t frame_out, size_t total_offset, long long total_out,
+                                         int want_total, hipStream_t stream)
 {
     const size_t n = (size_t)width * height;
     int grid = (int)((n + 255) / 256);
     if (grid > 8192)
         grid = 8192;
-    hipLaunchKernelGGL(r1_assemble_kernel, dim3(grid), dim3(256), 0, stream, (const uint8_t *)blocks, (uint8_t *)rgb, width, height,
-                       tile_w, tile_h, tiles_x, tiles_total, num_shards, tiles_per_shard, shard_stride, (unsigned long long *)total_rays);
+    hipLaunchKernelGGL(r1_assemble_kernel, dim3(grid, n_frames > 0 ? n_frames : 1), dim3(256), 0, stream, (const uint8_t *)blocks, (uint8_t *)rgb, width,
+                       height, tile_w, tile_h, tiles_x, num_shards, shard_stride, frame_in, frame_out, total_offset, total_out, want_total);
     return hipGetLastError();
 }
 

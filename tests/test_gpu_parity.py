@@ -336,6 +336,49 @@ def test_render_async_lands_the_frame_in_page_locked_host_memory(renderer):
         hf.close()
 
 
+def test_frame_batches_equal_single_frames(renderer):
+    """Frame batches (r1_render_batch_async / r1_render_shard_device_batch): n frames in ONE launch, the persistent waves
+    flowing from one frame into the next.  Every frame's pixels and ray count equal a synchronous r1_render of its seed —
+    whole frames and 3 shards x 2 frames through the gathered [shard][frame][record] layout, ragged size, odd tiles."""
+    torch = pytest.importorskip("torch")
+    w, h, spp, n = 211, 77, 3, 4
+    sc = r1.create_large_scene(w, h)
+    renderer.set_scene(sc)
+    want = [renderer.render(mp(w, h, spp, 40 + 3 * f))[:2] for f in range(n)]
+    hf = binding.HostFrames(w, h, n)
+    p = mp(w, h, spp, 40)
+    assert hf.record == binding.frame_record_bytes(p)
+    renderer.render_batch_async(p, n, hf, seed_stride=3)
+    renderer.sync()
+    for f in range(n):
+        assert hf.rays(f) == want[f][1], f
+        assert hf.image(f).tobytes() == want[f][0].tobytes(), f
+    # a shorter batch through the same context (partial last batch of a run), identical frames (stride 0)
+    renderer.render_batch_async(p, 2, hf, seed_stride=0)
+    renderer.sync()
+    assert hf.rays(0) == hf.rays(1) == want[0][1] and hf.image(1).tobytes() == want[0][0].tobytes()
+    hf.close()
+    # shards: 3 shards x 2 frames, 5x7 tiles; one "all-gather" = the shards' record arrays side by side
+    shards, nf, tw, th = 3, 2, 5, 7
+    want2 = [renderer.render(mp(w, h, spp, 90 + f, tile_w=tw, tile_h=th))[:2] for f in range(nf)]
+    p0 = mp(w, h, spp, 90, tile_w=tw, tile_h=th, shard=0, num_shards=shards)
+    rec, frec = binding.shard_record_bytes(p0), binding.frame_record_bytes(p0)
+    gathered = torch.zeros((shards, nf, rec), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for s_ in range(shards):
+        q = mp(w, h, spp, 90, tile_w=tw, tile_h=th, shard=s_, num_shards=shards)
+        renderer.render_shard_device_batch(q, nf, gathered[s_].data_ptr(), seed_stride=1, stream_ptr=stream)
+    frames = torch.zeros((nf, frec), dtype=torch.uint8, device="cuda")
+    renderer.assemble_device_records_batch(p0, nf, gathered.data_ptr(), frames.data_ptr(), stream)
+    torch.cuda.synchronize()
+    for f in range(nf):
+        assert frames[f, :w * h * 3].cpu().numpy().tobytes() == want2[f][0].tobytes(), f
+        assert int(frames[f, frec - 8:].view(torch.int64).item()) == want2[f][1], f
+    # variants without a throughput kernel refuse batches
+    with pytest.raises(r1.R1Error):
+        renderer.render_batch_async(mp(w, h, spp, 1, variant=binding.VARIANT_REFERENCE), 2, None)
+
+
 # ---- big scenes (BASELINE config 5 shape: the large generator scaled up) -------------------------
 
 
