@@ -126,6 +126,7 @@ struct r1_context
     bool tile_key_valid = false;
     uint32_t n_local_tiles = 0, total_samples = 0, full = 0;
 
+    int default_variant = 4; // what R1_VARIANT_DEFAULT resolves to for the scene in the context (r1_set_scene)
     int occupancy[48] = {0}; // [variant + 8 * big + 16 * mode]
     bool pixel_mode = false; // r1_set_pixel_mode
     DevBuf gstack; // blocks per CU of the trace kernel, by variant
@@ -382,6 +383,84 @@ static std::vector<R1Group> build_groups(uint32_t na, const std::vector<double> 
     return groups;
 }
 
+// ---- R1_VARIANT_DEFAULT for scenes of a few dozen spheres: measured, not guessed ---------------------------------
+// Between R1_TREE_SKIP_MIN and R1_TREE_SKIP_MAX hittable spheres neither kernel wins everywhere: the reference's
+// medium scene (46 spheres packed into a 9 x 2.3 x 8 box) is 4-5 % faster through the ungrouped exhaustive sweep,
+// slices of the large scene's lattice of the same size are 10-35 % faster through the tree
+// (profiles/r02/tree_vs_sweep_crossover.txt), and no cost estimate the builder can make tells the two kinds apart.
+// So a scene in that band is timed once per process: a probe frame (R1_PROBE_W x R1_PROBE_H x R1_PROBE_SPP with
+// the scene's own camera, one warm-up + two timed synchronous frames per kernel, the faster counts) decides, and
+// the verdict is remembered under a hash of the scene's arrays and camera, so the other contexts of the process — the
+// frames in flight of one renderer — and the `-n` runs of a host program do not measure again.  Both kernels produce
+// the same pixels; only the rate depends on the choice.  The probe costs ~3 ms, outside benchmark()'s repeated span.
+#include <map>
+#include <mutex>
+#define R1_PROBE_W 1200 // (a 600 x 400 x 4 probe is too small: launch and tail latency level the two kernels and it picked the sweep
+#define R1_PROBE_H 800  // on scenes where the tree is 13-25 % faster at 1200 x 800 x 10)
+#define R1_PROBE_SPP 4
+
+struct Batch;
+static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int block_layout, void *d_rays, hipStream_t st, bool throughput_mode,
+                         const Batch *batch = nullptr);
+
+static uint64_t fnv1a(uint64_t h, const void *data, size_t n)
+{
+    const unsigned char *b = (const unsigned char *)data;
+    for (size_t i = 0; i < n; ++i)
+        h = (h ^ b[i]) * 0x100000001B3ull;
+    return h;
+}
+
+static int choose_default_kernel(r1_context *c, const r1_scene *s, const r1_camera *cam)
+{
+    c->default_variant = 4;
+    if (c->n_active < R1_TREE_SKIP_MIN || c->n_active >= R1_TREE_SKIP_MAX)
+        return R1_OK;
+    static std::mutex mu;
+    static std::map<uint64_t, int> verdicts;
+    uint64_t h = 0xCBF29CE484222325ull;
+    const float *const src[9] = {s->center_x, s->center_y, s->center_z, s->radius_sq, s->inv_radius, s->albedo_r, s->albedo_g, s->albedo_b, s->mat_param};
+    for (int k = 0; k < 9; ++k)
+        h = fnv1a(h, src[k], (size_t)s->count * 4);
+    h = fnv1a(h, s->mat_type, s->count);
+    h = fnv1a(h, cam, sizeof(*cam));
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = verdicts.find(h);
+        if (it != verdicts.end())
+        {
+            c->default_variant = it->second;
+            return R1_OK;
+        }
+    }
+    r1_params p;
+    memset(&p, 0, sizeof(p));
+    p.width = R1_PROBE_W, p.height = R1_PROBE_H, p.spp = R1_PROBE_SPP, p.max_bounces = 50, p.seed = 10001;
+    p.tile_w = p.tile_h = 32, p.shard = 0, p.num_shards = 1;
+    int rc;
+    if ((rc = ensure(c->image, (size_t)p.width * p.height * 3 + 64)) || (rc = ensure(c->counters, R1_COUNTER_BYTES + 64)))
+        return rc;
+    double best[2] = {1e30, 1e30};
+    const int kinds[2] = {R1_VARIANT_PREFILTER, R1_VARIANT_BVH};
+    for (int round = 0; round < 3; ++round) // interleaved, so that a clock ramp treats both alike; round 0 warms up
+        for (int k = 0; k < 2; ++k)
+        {
+            p.variant = kinds[k];
+            if ((rc = enqueue_frame(c, &p, c->image.p, 0, (char *)c->counters.p + R1_COUNTER_BYTES, c->stream, false, nullptr)))
+                return rc;
+            R1_HIP(hipStreamSynchronize(c->stream));
+            float ms = 0;
+            R1_HIP(hipEventElapsedTime(&ms, c->last0, c->last2));
+            if (round > 0 && ms < best[k])
+                best[k] = ms;
+        }
+    c->default_variant = best[0] < best[1] ? 2 : 4;
+    c->tile_key_valid = false; // the caller's frames come next
+    std::lock_guard<std::mutex> lock(mu);
+    verdicts[h] = c->default_variant;
+    return R1_OK;
+}
+
 extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *cam)
 {
     if (!c || !s || !cam || !s->center_x || !s->center_y || !s->center_z || !s->radius_sq || !s->inv_radius || !s->mat_type ||
@@ -562,6 +641,11 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
     c->src_mat.assign(s->mat_type, s->mat_type + s->count);
     c->src_cam = *cam;
     c->have_scene = true;
+    if ((rc = choose_default_kernel(c, s, cam)))
+    {
+        c->have_scene = false;
+        return rc;
+    }
     return R1_OK;
 }
 
@@ -626,7 +710,7 @@ struct Batch
 
 // Enqueues trace + resolve on `st`. out/d_rays are device pointers.
 static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int block_layout, void *d_rays, hipStream_t st,
-                         bool throughput_mode, const Batch *batch = nullptr)
+                         bool throughput_mode, const Batch *batch)
 {
     const int n_frames = batch ? batch->n_frames : 1;
     if (!c->have_scene)
@@ -637,11 +721,11 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     int rc = r1_params_check(p);
     if (rc)
         return rc;
-    // kernel selection.  DEFAULT = the fastest validated kernel for the scene (measured, DESIGN.md
-    // §7): the box tree, except between R1_TREE_SKIP_MIN and R1_TREE_SKIP_MAX hittable spheres
-    // where the ungrouped exhaustive sweep is ahead (medium scene: 46).  PREFILTER always forces
-    // the exhaustive sweep, BVH always the tree; all of them produce the same pixels.
-    const bool tree_default = c->n_active < R1_TREE_SKIP_MIN || c->n_active >= R1_TREE_SKIP_MAX;
+    // kernel selection.  DEFAULT = the faster of the two validated kernels for the scene: the box tree, except
+    // that scenes of R1_TREE_SKIP_MIN .. R1_TREE_SKIP_MAX - 1 hittable spheres are MEASURED when they are set
+    // (choose_default_kernel: the ungrouped exhaustive sweep is ahead on the reference's dense medium scene, the tree
+    // on sparse scenes of the same size).  PREFILTER always forces the exhaustive sweep, BVH always the tree; all of
+    // them produce the same pixels.
     int variant = 2;
     switch (p->variant)
     {
@@ -650,7 +734,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     case R1_VARIANT_BVH: variant = 4; break;
     case R1_VARIANT_BVH_STATS: variant = 5; break;
     case R1_VARIANT_WAVEFRONT: variant = 6; break;
-    case R1_VARIANT_DEFAULT: variant = tree_default ? 4 : 2; break;
+    case R1_VARIANT_DEFAULT: variant = c->default_variant; break;
     default: variant = 2; break;
     }
     R1_HIP(hipSetDevice(c->device));

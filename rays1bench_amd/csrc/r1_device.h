@@ -37,8 +37,8 @@
 #define R1_BVH_STACK 32        // R1_VARIANT_BVH: per-lane traversal stack entries in LDS = most inner nodes on a path
 #define R1_BVH_TOP_NODES 63    // box tree: the first nodes in breadth-first order (6 levels); the big-scene kernels keep them in LDS (4 KB: 0 / 63 / 127 / 255 nodes -> 12.9 / 13.3 / 13.0 / 12.6 Grays/s on 100 004 spheres, the larger copies cost workgroups per CU)
 #define R1_BVH_LEAF 4          // spheres per leaf (<= 14; stored as pairs)
-#define R1_TREE_SKIP_MIN 9     // DEFAULT kernel: exhaustive sweep for scenes of [R1_TREE_SKIP_MIN, R1_TREE_SKIP_MAX) hittable
-#define R1_TREE_SKIP_MAX 128   // spheres, box tree otherwise
+#define R1_TREE_SKIP_MIN 9     // DEFAULT kernel: scenes of [R1_TREE_SKIP_MIN, R1_TREE_SKIP_MAX) hittable spheres are timed through the sweep AND the
+#define R1_TREE_SKIP_MAX 128   // tree when they are set (r1_capi.cpp choose_default_kernel); box tree otherwise
 #define R1_SUBQUEUES 16        // latency mode: sub-queues of the sample queue (R1TraceArgs::nq)
 #define R1_COUNTER_BYTES 4096  // per-context counter block: queue heads, ray count (+32), drain counts, stats (+128), sub-queues at +1024;
                                // the allocation carries 64 more bytes: the published ray count of the synchronous entry points

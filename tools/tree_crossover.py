@@ -38,8 +38,12 @@ def both(label):
                 ms.append(rend.last_timing()[1])
         res[name] = (statistics.median(ms), rays, out)
     same = res["sweep"][1] == res["tree"][1] and (res["sweep"][2] == res["tree"][2]).all()
-    print(f"{label}: sweep {res['sweep'][0]:.3f} ms  tree {res['tree'][0]:.3f} ms  -> {'tree' if res['tree'][0] < res['sweep'][0] else 'sweep'}  "
-          f"(rays {res['tree'][1]}, identical {same})")
+    rend.render_into(r1.make_params(w, h, spp, 10001), np.zeros((h, w, 3), np.uint8))
+    default = {binding.VARIANT_PREFILTER: "sweep", binding.VARIANT_BVH: "tree"}[rend.launch_info()["kernel"]]
+    faster = "tree" if res["tree"][0] < res["sweep"][0] else "sweep"
+    close = abs(res["tree"][0] - res["sweep"][0]) < 0.02 * min(res["tree"][0], res["sweep"][0])
+    print(f"{label}: sweep {res['sweep'][0]:.3f} ms  tree {res['tree'][0]:.3f} ms  -> {faster}  DEFAULT runs {default}"
+          f"{'' if default == faster else (' (within 2 %)' if close else ' (WRONG)')}  (rays {res['tree'][1]}, identical {same})")
 
 
 for name, make in (("small scene", r1.create_small_scene), ("medium scene", r1.create_medium_scene)):
