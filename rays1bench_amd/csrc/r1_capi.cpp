@@ -126,6 +126,9 @@ struct r1_context
     bool tile_key_valid = false;
     uint32_t n_local_tiles = 0, total_samples = 0, full = 0;
 
+    // one page-locked, device-visible word: the synchronous entry points let the frame's last launch store the ray count
+    // straight into host memory (8 bytes over PCIe at the end of r1_resolve_kernel) instead of enqueueing a second copy
+    unsigned long long *host_word = nullptr, *host_word_dev = nullptr;
     int default_variant = 4; // what R1_VARIANT_DEFAULT resolves to for the scene in the context (r1_set_scene)
     int occupancy[48] = {0}; // [variant + 8 * big + 16 * mode]
     bool pixel_mode = false; // r1_set_pixel_mode
@@ -209,6 +212,17 @@ extern "C" int r1_create(int device, r1_context **out)
         delete c;
         return R1_EHIP;
     }
+    if (hipHostMalloc((void **)&c->host_word, 64, hipHostMallocMapped) == hipSuccess)
+    {
+        if (hipHostGetDevicePointer((void **)&c->host_word_dev, c->host_word, 0) != hipSuccess)
+        {
+            (void)hipHostFree(c->host_word);
+            c->host_word = c->host_word_dev = nullptr;
+        }
+    }
+    else
+        c->host_word = nullptr; // (not fatal: the count is copied instead)
+    (void)hipGetLastError();
     c->cus = prop.multiProcessorCount;
     memset(&c->info, 0, sizeof(c->info));
     c->info.compute_units = c->cus;
@@ -228,6 +242,8 @@ extern "C" void r1_destroy(r1_context *c)
     release(c->wf_paths), release(c->wf_hits), release(c->wf_queue), release(c->wf_counts);
     release(c->gstack), release(c->counters), release(c->samples), release(c->image), release(c->batch_rays);
     release(c->wave_log);
+    if (c->host_word)
+        (void)hipHostFree(c->host_word);
     for (hipEvent_t e : c->ring)
         (void)hipEventDestroy(e);
     if (c->ev0)
@@ -1059,7 +1075,11 @@ static int render_host(r1_context *c, const r1_params *p, uint8_t *rgb_out, uint
         return rc;
     if ((rc = ensure(c->counters, R1_COUNTER_BYTES + 64)))
         return rc;
-    void *d_rays = (char *)c->counters.p + R1_COUNTER_BYTES; // behind the block the frame's last launch zeroes
+    // the ray count: stored by the frame's last launch straight into the context's page-locked word (no second copy to
+    // enqueue and wait for); the diagnostic builds count with atomics and keep a device word + copy
+    const bool stats = p->variant == R1_VARIANT_STATS || p->variant == R1_VARIANT_BVH_STATS;
+    const bool direct = !stats && c->host_word_dev;
+    void *d_rays = direct ? (void *)c->host_word_dev : (void *)((char *)c->counters.p + R1_COUNTER_BYTES); // (behind the block the frame's last launch zeroes)
     if ((rc = enqueue_frame(c, p, c->image.p, sharded ? 1 : 0, d_rays, c->stream, false)))
         return rc;
 
@@ -1067,14 +1087,16 @@ static int render_host(r1_context *c, const r1_params *p, uint8_t *rgb_out, uint
     if (!sharded)
     {
         R1_HIP(hipMemcpyAsync(rgb_out, c->image.p, img_bytes, hipMemcpyDeviceToHost, c->stream));
-        R1_HIP(hipMemcpyAsync(&rays, d_rays, 8, hipMemcpyDeviceToHost, c->stream));
+        if (!direct)
+            R1_HIP(hipMemcpyAsync(&rays, d_rays, 8, hipMemcpyDeviceToHost, c->stream));
         R1_HIP(hipStreamSynchronize(c->stream));
     }
     else
     {
         std::vector<uint8_t> block(out_bytes);
         R1_HIP(hipMemcpyAsync(block.data(), c->image.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
-        R1_HIP(hipMemcpyAsync(&rays, d_rays, 8, hipMemcpyDeviceToHost, c->stream));
+        if (!direct)
+            R1_HIP(hipMemcpyAsync(&rays, d_rays, 8, hipMemcpyDeviceToHost, c->stream));
         R1_HIP(hipStreamSynchronize(c->stream));
         const int tiles_x = (p->width + p->tile_w - 1) / p->tile_w;
         for (uint32_t lt = 0; lt < c->n_local_tiles; ++lt)
@@ -1088,6 +1110,8 @@ static int render_host(r1_context *c, const r1_params *p, uint8_t *rgb_out, uint
                        block.data() + ((size_t)lt * p->tile_h * p->tile_w + (size_t)ly * p->tile_w) * 3, (size_t)tw * 3);
         }
     }
+    if (direct)
+        rays = *(volatile unsigned long long *)c->host_word;
     if (num_rays_out)
         *num_rays_out = rays;
     if (device_seconds_out)

@@ -10,11 +10,14 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rays1bench_amd as r1
 
+from rays1bench_amd import binding
+
 w, h, spp = 1200, 800, 10
 rend = r1.Renderer(0)
+pinned = binding.HostFrame(w, h) if "pinned" in sys.argv[1:] else None  # r1_host_alloc'd pixel buffer instead of pageable numpy memory
 for name, mk in (("small", r1.create_small_scene), ("medium", r1.create_medium_scene), ("large", r1.create_large_scene)):
     sc = mk(w, h)
-    img = np.zeros((h, w, 3), np.uint8)
+    img = pinned.image if pinned else np.zeros((h, w, 3), np.uint8)
     p = r1.make_params(w, h, spp, 10001)
     rend.set_scene(sc)
     rend.render_into(p, img)
