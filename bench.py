@@ -37,10 +37,10 @@ VALU_ISSUE_PEAK_T = 1024 * 2.4e9 / 2 / 1e12  # wave-instructions/s: 256 CUs x 4 
 # Measured on one MI355X: one queue per frame in flight is the optimum (16 in flight on 16 queues
 # 1.18 ms per frame; 12 on 16: 1.77; 12 on 12: 1.20), 20 on 20 is 3 % better over a short run, and at 24 queues the
 # process runs out of hardware queues (10-24 Grays/s).  Ranks that also run RCCL (its stream needs a queue of its own)
-# therefore keep 16 frames in flight on 18 queues; one process driving N GPUs in-process runs one frame at a time.
+# keep 10 launches (of 2+ frames) in flight on 12 queues (run_ranks); one process driving N GPUs in-process runs one frame at a time.
 INFLIGHT_SINGLE, QUEUES_SINGLE = 20, 20
-INFLIGHT_RANK, QUEUES_RANK = 16, 18
-INFLIGHT_RANK_BATCHED = 8   # launches in flight per rank when every launch carries a batch of frames
+INFLIGHT_RANK, QUEUES_RANK = 10, 12
+INFLIGHT_RANK_BATCHED = 8   # launches in flight per rank when every launch carries a batch of N >= 3 frames
 QUEUES_CLIFF = 24
 
 
@@ -346,15 +346,18 @@ def run_ranks(args):
     n = world
     uses_rccl = (n > 1 and args.backend == "nccl") or args.rccl_selftest
     shards_ = max(n, args.emulate_shards, 1)
-    # Frames per launch (r1_render_shard_device_batch).  Measured per-rank rates on one MI355X carrying rank 0's tiles
-    # (profiles/r03/batch_sweep.txt): a rank's share of one frame is too small a launch at N >= 4 (8 shards: 23.3 Grays/s
-    # per rank with one frame per launch, 29.4 with 8; 4 shards: 28.2 -> 30.5; 2 shards: 32.0 either way; whole frames at
-    # N = 1: 32.5 alone, 30-31 batched), so N >= 3 ranks batch N frames per launch — when the run is long enough to keep
-    # ~16 launches busy (a 20-step run is better off with 20 small launches than with 3 large ones).
+    # Frames per launch (r1_render_shard_device_batch) and launches in flight for ranks.  Measured on one MI355X carrying
+    # rank 0's tiles with the rank path's all-gather through a one-rank RCCL communicator (profiles/r03/batch_sweep.txt):
+    #   * a rank's share of one frame is too small a launch at N >= 4 (8 shards: 23.3 Grays/s per rank with one frame per
+    #     launch, 29.4 with 8; 4 shards: 28.2 -> 30.5; 2 shards: 32.0 / 31.1; whole frames at N = 1: 32.5 alone, 30-31 batched);
+    #   * collectives issued from more than ~12 streams stall the submitting thread for ~7 ms every dozen launches (torch's
+    #     process group + the runtime's lazily mapped hardware queues): a 20-step run on 16 streams spends 9 of its 11 ms there.
+    # So ranks keep at most 10 launches in flight, of at least 2 frames each, and batch N frames per launch when the run is
+    # long enough to keep ~16 launches busy (a 20-step run is better off with 10 small launches than with 3 large ones).
     if args.batch <= 0:
-        args.batch = max(1, min(shards_, args.steps // 16)) if shards_ >= 3 and not args.pixel_mode else 1
+        args.batch = 1 if (shards_ == 1 or args.pixel_mode) else max(2, min(shards_, args.steps // 16))
     if args.inflight <= 0:
-        args.inflight = INFLIGHT_SINGLE if shards_ == 1 else (INFLIGHT_RANK if args.batch == 1 else INFLIGHT_RANK_BATCHED)
+        args.inflight = INFLIGHT_SINGLE if shards_ == 1 else (INFLIGHT_RANK if args.batch <= 2 else INFLIGHT_RANK_BATCHED)
     extra = QUEUES_RANK - INFLIGHT_RANK if uses_rccl else 0
     args.inflight = max(1, min(args.inflight, QUEUES_CLIFF - 1 - extra))  # launches' queues + RCCL's stay under the cliff
     set_hw_queues(args, args.inflight + extra)
@@ -524,13 +527,21 @@ def run_ranks(args):
         return elapsed, submit, ev
 
     # setup, not warm-up: frames through every slot so that its workspace (sample records, event ring, page-locked
-    # frame) is allocated before anything is timed, whatever --warmup is.  Two passes: the HIP runtime creates its
-    # hardware queues lazily, ~7 ms each, during the first ~40 submissions on 20 streams (tools/submit_times.py:
-    # five such stalls in the first pass, three in the second, none afterwards).
-    for _ in range(2):
+    # frames) is allocated before anything is timed, whatever --warmup is.  Repeated until a whole pass goes through
+    # without a stalled submission: the HIP runtime creates its hardware queues lazily, ~7 ms each, somewhere in the first
+    # dozens of submissions on 16-20 streams (tools/submit_times.py: five such stalls in the first pass over 20 slots,
+    # three in the second, none afterwards; a 20-step run that meets two of them is 16 ms late on a 17 ms job).
+    setup_passes = 0
+    for _ in range(8):
+        worst = 0.0
         for _ in range(B * len(slots)):
+            t_ = time.perf_counter()
             step()
+            worst = max(worst, time.perf_counter() - t_)
         fence()
+        setup_passes += 1
+        if setup_passes >= 2 and worst < 2e-3:
+            break
     for _ in range(args.warmup):
         step()
     fence()
@@ -680,7 +691,7 @@ def run_ranks(args):
             "workgroups": info["blocks"], "threads_per_workgroup": info["threads_per_block"],
             "frames_in_flight": len(slots) * B, "launches_in_flight": len(slots), "frames_per_launch": B,
             "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
-            "host_submit_ms_per_step": submit / args.steps * 1e3,
+            "host_submit_ms_per_step": submit / args.steps * 1e3, "setup_passes": setup_passes,
             "kernel": kernel_name})
         if is_tree:
             cfg["bvh"] = {"nodes": info["bvh_nodes"], "leaves": info["bvh_leaves"], "depth": info["bvh_depth"]}
