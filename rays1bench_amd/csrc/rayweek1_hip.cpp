@@ -62,6 +62,8 @@ static int g_device = 0;
 static int g_variant = R1_VARIANT_DEFAULT;
 static int g_devices = 1;
 static int g_backend = 0; // 0 hip, 1 cpu-step1, 12 cpu-step12
+static int g_pipeline = 0; // --pipeline FRAMES: after the benchmark() runs, FRAMES frames per scene with several in flight (r1_render_async)
+static int g_inflight = 20;
 int r1cpu_step12_render(const r1_scene *scene, const r1_camera *cam, int width, int height, int spp, int max_bounces, uint8_t *rgb,
                         uint64_t *num_rays); // r1_cpu_backends.cpp
 int r1cpu_step1_render(int scene_kind, const r1_scene *scene, const r1_camera *cam, int width, int height, int spp, uint8_t *rgb,
@@ -307,6 +309,76 @@ static void log_json(const char *version, const char *scene, const RESULT *resul
     fclose(f);
 }
 
+// ---- frames in flight from the C++ host (no reference counterpart: benchmark() renders ONE frame and waits) --------
+// The `-n` runs of main (rayweek1.cpp:969-984) are independent frames.  Rendered one after the other each pays the
+// tail of its own longest bounce chains; kept in flight — one context, stream and page-locked pixel buffer per frame,
+// r1_render_async — the next frames fill the chip while one drains, and every frame still ends with its pixels and
+// ray count on the host (the Timer span of rayweek1.cpp:848 -> :891, pipelined).  Prints one line per scene.
+static int pipelined(const char *scene_name, int kind, int frames)
+{
+    const int k = g_inflight < frames ? g_inflight : frames;
+    r1_host_scene *hs = nullptr;
+    if (r1_host_scene_create(kind, g_screen_w, g_screen_h, 0, 0, &hs) != R1_OK)
+        return 1;
+    r1_params p;
+    memset(&p, 0, sizeof(p));
+    p.width = g_screen_w, p.height = g_screen_h, p.spp = g_spp, p.max_bounces = g_max_bounces, p.seed = g_seed;
+    p.tile_w = 32, p.tile_h = 32, p.shard = 0, p.num_shards = 1, p.variant = g_variant;
+    const size_t img = (size_t)g_screen_w * g_screen_h * 3, rec = ((img + 7) & ~(size_t)7) + 8;
+    std::vector<r1_context *> ctx((size_t)k, nullptr);
+    std::vector<uint8_t *> host((size_t)k, nullptr);
+    int rc = R1_OK;
+    const int visible = r1_device_count();
+    for (int i = 0; i < k && rc == R1_OK; ++i) // every context first, the scenes afterwards: the streams get their own hardware queues
+        rc = r1_create(g_device % (visible > 0 ? visible : 1), &ctx[(size_t)i]);
+    for (int i = 0; i < k && rc == R1_OK; ++i)
+    {
+        rc = r1_set_scene(ctx[(size_t)i], r1_host_scene_spheres(hs), r1_host_scene_camera(hs));
+        if (rc == R1_OK)
+            rc = r1_host_alloc(rec, (void **)&host[(size_t)i]);
+    }
+    uint64_t rays = 0;
+    double secs = 0;
+    if (rc == R1_OK)
+    {
+        for (int pass = 0; pass < 2 && rc == R1_OK; ++pass) // pass 0: workspaces and queues (not timed)
+        {
+            rays = 0;
+            auto t0 = std::chrono::high_resolution_clock::now();
+            for (int f = 0; f < (pass ? frames : k) && rc == R1_OK; ++f)
+            {
+                const size_t s = (size_t)(f % k);
+                if (f >= k) // the slot's previous frame has to have landed before its buffer is reused
+                {
+                    rc = r1_sync(ctx[s]);
+                    rays += *(const uint64_t *)(host[s] + rec - 8);
+                }
+                if (rc == R1_OK)
+                    rc = r1_render_async(ctx[s], &p, host[s], (uint64_t *)(host[s] + rec - 8), nullptr);
+            }
+            for (int i = 0; i < k && rc == R1_OK; ++i)
+            {
+                rc = r1_sync(ctx[(size_t)i]);
+                if (i < (pass ? frames : k))
+                    rays += *(const uint64_t *)(host[(size_t)i] + rec - 8);
+            }
+            secs = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+        }
+    }
+    if (rc == R1_OK)
+        printf("%s pipelined:  %d frames, %d in flight, %.3f ms per frame, %llu rays, %0.2f mrays/s (pixels + count on the host)\n", scene_name, frames,
+               k, secs / frames * 1e3, (unsigned long long)rays, rays / secs / 1e6);
+    else
+        fprintf(stderr, "pipelined %s: %s\n", scene_name, r1_last_error());
+    for (int i = 0; i < k; ++i)
+    {
+        r1_host_free(host[(size_t)i]);
+        r1_destroy(ctx[(size_t)i]);
+    }
+    r1_host_scene_destroy(hs);
+    return rc == R1_OK ? 0 : 1;
+}
+
 int main(int argc, const char *argv[])
 {
     bool write_tga = false;
@@ -340,6 +412,10 @@ int main(int argc, const char *argv[])
             g_devices = atoi(argv[++i]);
         else if (strcmp(argv[i], "--variant") == 0 && i + 1 < argc)
             g_variant = atoi(argv[++i]);
+        else if (strcmp(argv[i], "--pipeline") == 0 && i + 1 < argc)
+            g_pipeline = atoi(argv[++i]);
+        else if (strcmp(argv[i], "--inflight") == 0 && i + 1 < argc)
+            g_inflight = atoi(argv[++i]);
         else if (strcmp(argv[i], "--backend") == 0 && i + 1 < argc)
         {
             const char *b = argv[++i];
@@ -357,6 +433,15 @@ int main(int argc, const char *argv[])
         return 1;
     }
 
+    if (g_pipeline > 0 && g_backend == 0)
+    {
+        // Frames in flight only overlap when their streams sit on different hardware queues; the ROCm default is 4.  One queue
+        // per frame in flight + one for the context benchmark() renders through (two streams that share a queue run their frames
+        // one after the other); at most 23: beyond that the process runs out of them.  Must be set before the first HIP call.
+        char q[16];
+        snprintf(q, sizeof(q), "%d", g_inflight < 1 ? 2 : (g_inflight > 22 ? 23 : g_inflight + 1));
+        setenv("GPU_MAX_HW_QUEUES", q, 0);
+    }
     // HIP context creation stays outside the timed region and is shared by all -n runs.
     // Devices wrap around the visible ones, so --devices 2 also works (oversubscribed) on one GPU.
     const int visible = g_backend == 0 ? r1_device_count() : 0;
@@ -406,9 +491,17 @@ int main(int argc, const char *argv[])
     log_results(version, "large", results, num_runs);
     log_json(version, "large", results, num_runs);
 
+    int rc_pipe = 0;
+    if (g_pipeline > 0 && g_backend == 0 && g_inflight >= 1 && g_inflight <= 64)
+    {
+        rc_pipe |= pipelined("small", R1_SCENE_SMALL, g_pipeline);
+        rc_pipe |= pipelined("medium", R1_SCENE_MEDIUM, g_pipeline);
+        rc_pipe |= pipelined("large", R1_SCENE_LARGE, g_pipeline);
+    }
+
     delete[] pixels;
     for (r1_context *c : g_ctx)
         r1_destroy(c);
     r1_multi_destroy(g_multi);
-    return 0;
+    return rc_pipe ? 3 : 0;
 }

@@ -29,9 +29,9 @@ def fracs(node, path=""):
 
 def test_committed_bench_line_has_the_contract_fields():
     path, d = latest_line()
-    assert os.path.basename(os.path.dirname(path)) >= "r02", "the round's line has not been committed"
+    assert os.path.basename(os.path.dirname(path)) >= "r03", "the round's line has not been committed"
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-              "data", "config", "roofline", "cpu_baseline", "value_dispatch_to_host"):
+              "data", "config", "roofline", "cpu_baseline", "value_dispatch_to_host", "value_device_resident"):
         assert k in d, k
     baseline = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert d["unit"] == "mrays/s" and "large" in d["metric"] and "1200x800x10" in d["metric"]
@@ -39,25 +39,31 @@ def test_committed_bench_line_has_the_contract_fields():
     assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "strong" and d["vs_baseline"] is None
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - d["config"]["rays_per_step"] / d["ms_per_step"] / 1e3) < 1e-6 * d["value"]
-    assert "in flight" in d["config"]["value_mode"]
+    # `value` times the survey's span — every frame in flight ends with its pixels + count on the HOST
+    mode = d["config"]["value_mode"]
+    assert "in flight" in mode and "page-locked HOST memory" in mode and "rayweek1.cpp:848 -> :891" in mode
+    r = d["value_device_resident"]
+    assert r["unit"] == "mrays/s" and "left in HBM" in r["mode"] and 0.8 * d["value"] < r["value"] < 1.25 * d["value"]
 
 
 def test_roofline_describes_the_timed_kernel_and_no_frac_exceeds_one():
     _, d = latest_line()
     r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel_ms", "flop_per_launch", "work", "launch_overlap",
-              "achieved_aggregate", "frac_aggregate", "hbm"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "flop_per_launch", "flop_per_frame", "work", "launch_overlap",
+              "per_launch", "valu_issue", "hbm"):
         assert k in r, k
     for where, v in fracs(d):
         assert 0 <= v <= 1, (where, v)
     assert r["bound"] == "valu" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
-    # achieved = executed flop per launch / average launch duration; frac = achieved / peak
-    assert abs(r["achieved"] - r["flop_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e12) < 1e-9 * r["achieved"]
+    # `achieved` / `frac` are the AGGREGATE figures: executed flop of the frames of the timed region / its wall time
+    assert abs(r["achieved"] - r["flop_per_frame"] / (d["ms_per_step"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert abs(r["frac_aggregate"] - r["achieved_aggregate"] / r["peak"]) < 1e-12
-    # the aggregate is the same flop over the wall time of the timed region (launches overlap)
-    assert abs(r["achieved_aggregate"] - r["flop_per_launch"] / (d["ms_per_step"] * 1e-3) / 1e12) < 1e-6 * r["achieved_aggregate"]
-    assert abs(r["launch_overlap"] - r["kernel_ms"] / d["ms_per_step"]) < 0.05 * r["launch_overlap"]
+    # the per-launch figure (flop per launch / that launch's own duration under overlap) lives in a sub-record
+    pl = r["per_launch"]
+    assert abs(pl["achieved"] - r["flop_per_launch"] / (pl["kernel_ms"] * 1e-3) / 1e12) < 1e-9 * pl["achieved"]
+    assert abs(pl["frac"] - pl["achieved"] / r["peak"]) < 1e-12 and pl["frac"] <= r["frac"]
+    assert abs(r["launch_overlap"] - pl["kernel_ms"] / (d["ms_per_step"] * r["frames_per_launch"])) < 0.05 * r["launch_overlap"]
+    assert abs(r["flop_per_launch"] - r["flop_per_frame"] * r["frames_per_launch"]) < 1e-6 * r["flop_per_launch"]
     # executed work: measured counts x the stated flop per unit
     w = r["work"]
     assert w["rays_per_launch"] == d["config"]["rays_per_step"]
@@ -67,25 +73,29 @@ def test_roofline_describes_the_timed_kernel_and_no_frac_exceeds_one():
         assert 0 < w["lane_utilisation"]["node_loop"] <= 1 and 0 < w["lane_utilisation"]["leaf_loop"] <= 1
     else:
         flop = w["rays_per_launch"] * w["group_tests_per_ray"] * w["flop_per_group_test"] + w["rays_per_launch"] * w["exact_slots_per_ray"] * w["flop_per_exact_slot"]
-    assert abs(flop - r["flop_per_launch"]) < 1e-6 * flop
+    assert abs(flop - r["flop_per_frame"]) < 1e-6 * flop
     assert flop < 16.0 * 488 * w["rays_per_launch"]  # far below the reference-equivalent count: that model is not in `roofline`
-    # HBM traffic: either absent or labelled with where it was measured; its fraction is of the 8 TB/s peak
+    # HBM traffic and VALU issue: either absent or labelled with where they were measured
     assert (r["traffic"] is None) == (r["traffic_source"] is None)
     if r["traffic"] is not None:
         assert "profiles/" in r["traffic_source"] and os.path.exists(os.path.join(ROOT, "profiles", "pmc_traffic.json"))
-        assert r["hbm"]["peak"] == 8000.0 and 0 < r["hbm"]["frac_aggregate"] < 1
-        assert abs(r["hbm"]["achieved_aggregate"] - r["traffic"] / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * r["hbm"]["achieved_aggregate"]
+        assert r["hbm"]["peak"] == 8000.0 and 0 < r["hbm"]["frac"] < 1
+        assert abs(r["hbm"]["achieved"] - r["traffic"] / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * r["hbm"]["achieved"]
+        v = r["valu_issue"]
+        assert "profiles/r0" in v["source"] and 0 < v["frac"] <= 1 and 0 < v["active_lane_fraction"] <= 1
+        assert abs(v["achieved"] - v["wave_instructions_per_launch"] / (d["ms_per_step"] * 1e-3) / 1e12) < 1e-6 * v["achieved"]
 
 
 def test_dispatch_to_host_cpu_baseline_and_sweep_subrecord():
     _, d = latest_line()
     v = d["value_dispatch_to_host"]
-    assert v["unit"] == "mrays/s" and 0 < v["value"] <= d["value"] * 1.05 and "rayweek1.cpp:848" in v["span"]
+    assert v["unit"] == "mrays/s" and 0 < v["value"] <= d["value"] * 1.05 and "rayweek1.cpp:848" in v["span"] and "synchronous" in v["span"]
     assert abs(v["value"] - d["config"]["rays_per_step"] / v["ms_per_step"] / 1e3) < 1e-6 * v["value"]
     assert v["device_ms_per_step"] <= v["ms_per_step"]
     c = d["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample", "cpu_model"):
+    for k in ("value", "unit", "cores", "kind", "sample", "cpu_model", "note"):
         assert k in c, k
+    assert "thread" in c["note"]  # say next to the number what it mostly measures at this frame size
     assert c["kind"] in ("reference", "port") and c["unit"] == "mrays/s" and c["cores"] >= 1 and len(c["cpu_model"]) > 3
     if "box tree" in d["config"].get("kernel", ""):
         e = d["exhaustive_sweep"]

@@ -375,6 +375,25 @@ def test_rayweek1_hip_gather_rccl_one_device(tmp_path):
         assert re.fullmatch(r"hip\|\d+\.\d{3}s\|\d+\|\d+\.\d{3} mrays/s\|", open(tmp_path / "b" / f"out_{n}.txt").read())
 
 
+def test_rayweek1_hip_pipeline_mode_counts_the_same_rays(tmp_path):
+    """rayweek1_hip --pipeline FRAMES: the C++ host keeps frames in flight through r1_render_async (one context +
+    page-locked buffer per frame) after its benchmark() runs; every pipelined frame is the frame benchmark() rendered,
+    so FRAMES frames count FRAMES x its rays."""
+    import re
+    import subprocess
+    import os
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rays1bench_amd", "lib", "rayweek1_hip")
+    out = subprocess.run([exe, "--width", "160", "--height", "96", "--spp", "3", "--pipeline", "7", "--inflight", "3"], cwd=tmp_path,
+                         capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()
+    text = out.stdout.decode()
+    single = dict(zip(("small", "medium", "large"), (int(v) for v in re.findall(r"total rays:     (\d+)", text))))
+    for name in ("small", "medium", "large"):
+        m = re.search(rf"{name} pipelined:  7 frames, 3 in flight, [\d.]+ ms per frame, (\d+) rays, [\d.]+ mrays/s", text)
+        assert m, text
+        assert int(m.group(1)) == 7 * single[name]
+
+
 # ---- PIXEL mode of the throughput entry point (r1_set_pixel_mode) --------------------------------------
 
 

@@ -8,7 +8,7 @@ import json
 import os
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles", tag)
@@ -32,6 +32,47 @@ counters = {"command": cmd, "workload": "large 1200x800x10",
             "exhaustive sweep, frames in flight (MODE 0)": {k: v[0] for k, v in {**means("pmc_sq1", sw), **means("pmc_sq2", sw)}.items()},
             "note": "SQ_INSTS_VALU = VALU wave-instructions per launch (one frame); round 1's tree kernel: 888 M."}
 json.dump(counters, open(f"{dst}/pmc_counters_tree_kernel.json", "w"), indent=1)
+
+
+# ---- the same counters at the TIMED configuration (20 frames in flight) + how much the dispatches overlapped under collection
+def overlap_of(c, match):
+    """sum of the kernel's durations / span from its first start to its last end, from the kernel trace of the same run"""
+    rows = []
+    for f in glob.glob(f"{out}/{c}/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if match in r["Kernel_Name"]:
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    if not rows:
+        return None
+    rows.sort()
+    rows = rows[len(rows) // 3:]  # skip the setup and warm-up launches
+    busy = sum(b - a for a, b in rows)
+    return {"dispatches": len(rows), "mean_duration_ms": busy / len(rows) / 1e6, "overlap": busy / max(rows[-1][1] - rows[0][0], 1)}
+
+
+c20 = {**means("pmc20_sq1", tp), **means("pmc20_sq2", tp)}
+if c20:
+    v = {k: x[0] for k, x in c20.items()}
+    ov = overlap_of("pmc20_sq2", tp) or overlap_of("pmc20_sq1", tp)
+    derived = {}
+    if "SQ_ACTIVE_INST_VALU" in v and "SQ_WAVE_CYCLES" in v:
+        # SQ_* cycle counters count quad-cycles summed over waves (MI355X_MICROARCH.md: s_memtime tick vs SQ PMC units)
+        derived["valu_share_of_wave_cycles"] = v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"]
+        derived["wait_any_share_of_wave_cycles"] = v.get("SQ_WAIT_ANY", 0) / v["SQ_WAVE_CYCLES"]
+        derived["wait_inst_any_share_of_wave_cycles"] = v.get("SQ_WAIT_INST_ANY", 0) / v["SQ_WAVE_CYCLES"]
+    if "SQ_THREAD_CYCLES_VALU" in v and "SQ_ACTIVE_INST_VALU" in v:
+        derived["valu_active_lane_fraction"] = v["SQ_THREAD_CYCLES_VALU"] / (64 * v["SQ_ACTIVE_INST_VALU"])
+    if "SQ_ACTIVE_INST_VALU" in v and "SQ_BUSY_CYCLES" in v:
+        # a SIMD issues one VALU instruction of one wave at a time: busy VALU quad-cycles summed over waves / (SQ busy cycles x 4 SIMDs per CU ... per SE)
+        derived["valu_quadcycles_per_sq_busy_cycle"] = v["SQ_ACTIVE_INST_VALU"] / v["SQ_BUSY_CYCLES"]
+    json.dump({"command": "rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --no-cpu-baseline --no-extras --steps 40 --warmup 20 "
+                          "(20 frames in flight: the timed configuration); mean per dispatch of r1_trace_kernel<4,false,false,0>",
+               "workload": "large 1200x800x10", "counters": v, "dispatch_overlap_under_collection": ov, "derived": derived,
+               "note": "rocprofv3 reads the counters per dispatch; `dispatch_overlap_under_collection` says whether the 20 frames in flight still "
+                       "overlapped while it did (1.0 = one dispatch at a time: then the wait / busy figures describe an isolated launch, "
+                       "whatever --inflight says, and only the instruction counts transfer to the timed run)"},
+              open(f"{dst}/pmc_counters_tree_kernel_inflight20.json", "w"), indent=1)
+    print("inflight 20:", derived, ov)
 f, w, fp, wp = means("pmc_FETCH_SIZE", tp), means("pmc_WRITE_SIZE", tp), means("pmcpix_FETCH_SIZE", pix), means("pmcpix_WRITE_SIZE", pix)
 fl, wl, fs, ws = means("pmc_FETCH_SIZE", lat), means("pmc_WRITE_SIZE", lat), means("pmc_FETCH_SIZE", sw), means("pmc_WRITE_SIZE", sw)
 hb = lambda a, b: (2 * a["FETCH_SIZE"][0] + b["WRITE_SIZE"][0]) * 1024
@@ -54,7 +95,19 @@ json.dump(traffic, open(f"{dst}/pmc_hbm_traffic.json", "w"), indent=1)
 ms = {str(k): json.loads(open(f"{out}/emulate_shards_{k}.json").read())["ms_per_step"] for k in (2, 4, 8)}
 one = json.loads(open(f"{out}/bench_line.json").read().strip().splitlines()[-1])["ms_per_step"]
 ms["1"] = one
-em = {"command": "python bench.py --steps 200 --warmup 20 --no-cpu-baseline --emulate-shards N (one GPU carries rank 0's tiles of an N-GPU run; no collective); N = 1: the bench line",
+short = {}
+for k in (2, 4, 8):
+    try:
+        short[str(k)] = json.loads(open(f"{out}/emulate_shards_{k}_steps20.json").read())["ms_per_step"]
+    except Exception:
+        pass
+try:
+    short["1"] = json.loads(open(f"{out}/bench_line_driver_command.json").read().strip().splitlines()[-1])["ms_per_step"]
+except Exception:
+    pass
+em = {"command": "python bench.py --steps 320 --warmup 32 --no-cpu-baseline --no-extras --emulate-shards N --rccl-selftest (one GPU carries rank 0's tiles of an N-GPU run through "
+                 "the rank path: frame batches, one RCCL all-gather per launch through a one-rank communicator, copies to the host); N = 1: the bench line",
+      "ms_per_frame_steps20": short,
       "ms_per_frame": ms, "fraction_of_ideal": {k: one / int(k) / v for k, v in ms.items() if k != "1"},
       "note": "single-GPU emulation of the per-rank load; the N-GPU run itself is the driver's"}
 json.dump(em, open(f"{dst}/emulated_shards.json", "w"), indent=1)

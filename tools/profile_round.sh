@@ -6,7 +6,7 @@
 #   3. SQ counters of the throughput-mode trace kernel (instruction counts, busy / wait cycles)
 #   4. the bench line itself (with cpu_baseline), the other BASELINE configs on one GPU, emulated per-rank loads
 #   5. diagnostics: traversal counters, per-wave timeline of a synchronous frame, tree against sweep by sphere count, issue-cost and atomic micro-benchmarks
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT && mkdir -p $OUT
@@ -19,6 +19,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 timeout -k 10 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace -d $OUT/pmc_sq1 -o p --output-format csv -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 --inflight 1 > $OUT/pmc_sq1.log 2>&1 || echo "pmc sq1 failed"
 timeout -k 10 120 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE SQ_ACTIVE_INST_LDS --kernel-trace -d $OUT/pmc_sq2 -o p --output-format csv -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 --inflight 1 > $OUT/pmc_sq2.log 2>&1 || echo "pmc sq2 failed"
+# the same two SQ passes at the TIMED configuration (20 frames in flight).  Whether the dispatches still overlap
+# under counter collection shows in the kernel trace of the same run (tools/collect_profiles.py reports the overlap it finds).
+timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc20_sq1 -o p --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-extras --steps 40 --warmup 20 > $OUT/pmc20_sq1.log 2>&1 || echo "pmc20 sq1 failed"
+timeout -k 10 200 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc20_sq2 -o p --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-extras --steps 40 --warmup 20 > $OUT/pmc20_sq2.log 2>&1 || echo "pmc20 sq2 failed"
 cd $R
 timeout -k 10 300 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err || echo "bench failed"
 timeout -k 10 120 python bench.py --steps 20 --warmup 5 > $OUT/bench_line_driver_command.json 2>/dev/null || echo "bench20 failed"
@@ -27,8 +31,10 @@ timeout -k 10 200 python bench.py --spp 250 --steps 48 --warmup 16 --no-cpu-base
 timeout -k 10 300 python bench.py --scene grid --width 1920 --height 1080 --spp 64 --steps 16 --warmup 4 --inflight 4 > $OUT/bench_line_config5_100k_one_gpu.json 2>/dev/null || echo "config5 failed"
 timeout -k 10 200 python bench.py --pixel-mode --no-cpu-baseline > $OUT/bench_line_pixel_mode.json 2>/dev/null || echo "pixel failed"
 for k in 2 4 8; do
-  timeout -k 10 120 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --emulate-shards $k 2>/dev/null | tail -1 > $OUT/emulate_shards_$k.json || echo "emulate $k failed"
+  timeout -k 10 120 python bench.py --steps 320 --warmup 32 --no-cpu-baseline --no-extras --emulate-shards $k --rccl-selftest 2>/dev/null | tail -1 > $OUT/emulate_shards_$k.json || echo "emulate $k failed"
+  timeout -k 10 120 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --emulate-shards $k --rccl-selftest 2>/dev/null | tail -1 > $OUT/emulate_shards_${k}_steps20.json || echo "emulate $k short failed"
 done
+timeout -k 10 120 python bench.py --gpus 1 --multi inproc --steps 50 --warmup 5 --check > $OUT/bench_line_inproc_one_gpu.json 2>/dev/null || echo "inproc failed"
 timeout -k 10 120 python tools/bvh_stats.py large 1200 800 10 > $OUT/traversal_stats_tree_kernel.txt 2>&1
 timeout -k 10 120 python tools/kernel_stats.py large 1200 800 10 > $OUT/phase_stats_sweep_kernel.txt 2>&1
 timeout -k 10 120 python tools/wave_timeline.py > $OUT/wave_timeline_sync_frame.txt 2>&1
@@ -42,7 +48,7 @@ out = "$OUT"
 for tag in ("k16", "k20"):
     for f in glob.glob(f"{out}/{tag}/**/*kernel_stats.csv", recursive=True):
         print(tag, *open(f).read().splitlines()[:4], sep="\n   ")
-for c in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmcpix_FETCH_SIZE", "pmcpix_WRITE_SIZE", "pmc_sq1", "pmc_sq2"):
+for c in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmcpix_FETCH_SIZE", "pmcpix_WRITE_SIZE", "pmc_sq1", "pmc_sq2", "pmc20_sq1", "pmc20_sq2"):
     for f in glob.glob(f"{out}/{c}/**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
