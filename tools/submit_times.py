@@ -46,7 +46,9 @@ if "dummypre" in sys.argv[4:]:
     _dummy = raw_streams(slots_n)  # created, never used
 w, h, spp = 1200, 800, 10
 sc = r1.create_large_scene(w, h)
-p = r1.make_params(w, h, spp, 10001)
+tile = [int(a[5:]) for a in sys.argv[4:] if a.startswith("tile=")]
+tw, th = (tile[0], tile[0]) if tile else (32, 32)
+p = r1.make_params(w, h, spp, 10001, tile_w=tw, tile_h=th)
 ctx = []
 extra = slots_n if "last" in sys.argv[4:] else 0  # "last": twice as many contexts, only the later half is used
 if "split" in sys.argv[4:]:  # all contexts (and their streams) first, scenes afterwards
