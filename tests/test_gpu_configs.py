@@ -375,6 +375,54 @@ def test_rayweek1_hip_gather_rccl_one_device(tmp_path):
         assert re.fullmatch(r"hip\|\d+\.\d{3}s\|\d+\|\d+\.\d{3} mrays/s\|", open(tmp_path / "b" / f"out_{n}.txt").read())
 
 
+@pytest.mark.parametrize("case", ["sweep_small", "tree_big", "sweep_big", "medium_default", "empty_shards"])
+def test_frame_batches_through_every_throughput_kernel(case):
+    """Frame batches (MODE 3 builds of the throughput kernels) for the kernels tests/test_gpu_parity.py does not reach: the
+    exhaustive sweep, the big-scene tree and sweep kernels (> 1023 spheres), a scene in DEFAULT's measured band, and shards
+    that own no tile.  Every frame of a batch = r1_render of its seed."""
+    torch = pytest.importorskip("torch")
+    variant, shards, tw, th = binding.VARIANT_DEFAULT, 1, 32, 32
+    if case == "sweep_small":
+        sc, w, h, spp, variant = r1.create_large_scene(150, 90), 150, 90, 3, binding.VARIANT_PREFILTER
+    elif case == "tree_big":
+        sc, w, h, spp = r1.create_grid_scene(128, 96, 50, 32), 128, 96, 3
+    elif case == "sweep_big":
+        sc, w, h, spp, variant = r1.create_grid_scene(96, 64, 40, 30), 96, 64, 2, binding.VARIANT_PREFILTER
+    elif case == "medium_default":
+        sc, w, h, spp = r1.create_medium_scene(150, 90), 150, 90, 3
+    else:  # one 32x32 tile, three shards: shards 1 and 2 own nothing
+        sc, w, h, spp, shards = r1.create_small_scene(30, 20), 30, 20, 4, 3
+    rend = r1.Renderer(0)
+    rend.set_scene(sc)
+    n = 3
+    want = [rend.render(r1.make_params(w, h, spp, 500 + 7 * f, variant=variant, tile_w=tw, tile_h=th))[:2] for f in range(n)]
+    if shards == 1:
+        hf = binding.HostFrames(w, h, n)
+        rend.render_batch_async(r1.make_params(w, h, spp, 500, variant=variant), n, hf, seed_stride=7)
+        rend.sync()
+        for f in range(n):
+            assert hf.rays(f) == want[f][1], (case, f)
+            assert hf.image(f).tobytes() == want[f][0].tobytes(), (case, f)
+        hf.close()
+    else:
+        p0 = r1.make_params(w, h, spp, 500, variant=variant, shard=0, num_shards=shards)
+        rec, frec = binding.shard_record_bytes(p0), binding.frame_record_bytes(p0)
+        gathered = torch.full((shards, n, rec), 0xAB, dtype=torch.uint8, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        for s_ in range(shards):
+            rend.render_shard_device_batch(r1.make_params(w, h, spp, 500, variant=variant, shard=s_, num_shards=shards), n, gathered[s_].data_ptr(),
+                                           seed_stride=7, stream_ptr=st)
+        frames = torch.zeros((n, frec), dtype=torch.uint8, device="cuda")
+        rend.assemble_device_records_batch(p0, n, gathered.data_ptr(), frames.data_ptr(), st)
+        torch.cuda.synchronize()
+        for f in range(n):
+            assert frames[f, :w * h * 3].cpu().numpy().tobytes() == want[f][0].tobytes(), (case, f)
+            assert int(frames[f, frec - 8:].view(torch.int64).item()) == want[f][1], (case, f)
+            for s_ in (1, 2):  # tile-less shards: count 0
+                assert int(gathered[s_, f, rec - 8:].view(torch.int64).item()) == 0
+    rend.close()
+
+
 def test_rayweek1_hip_pipeline_mode_counts_the_same_rays(tmp_path):
     """rayweek1_hip --pipeline FRAMES: the C++ host keeps frames in flight through r1_render_async (one context +
     page-locked buffer per frame) after its benchmark() runs; every pipelined frame is the frame benchmark() rendered,

@@ -240,3 +240,21 @@ def test_cpu_backends_are_named_choices_of_the_host_program_only():
     if r1.device_count() == 0:
         hip = subprocess.run([exe, "--width", "16", "--height", "16", "--spp", "1"], capture_output=True, timeout=60)
         assert hip.returncode != 0 and b"HIP" in hip.stderr
+
+
+def test_record_sizes_keep_the_ray_counts_aligned():
+    """r1_shard_record_bytes / r1_frame_record_bytes (host arithmetic, no GPU): the uint64 ray count behind a tile block or an
+    image is 8-byte aligned for any tile and image size, and sharding.py mirrors the C arithmetic."""
+    from rays1bench_amd import sharding
+    for w, h, shards, tw, th in ((1200, 800, 8, 32, 32), (93, 61, 3, 5, 7), (7, 5, 2, 3, 3), (1, 1, 1, 1, 1), (1921, 1081, 5, 31, 17)):
+        p = r1.make_params(w, h, 2, 1, tile_w=tw, tile_h=th, shard=0, num_shards=shards)
+        block, rec, frame = binding.shard_block_bytes(p), binding.shard_record_bytes(p), binding.frame_record_bytes(p)
+        assert rec % 8 == 0 and rec - 8 >= block and rec - 16 < block
+        assert frame % 8 == 0 and frame - 8 >= w * h * 3 and frame - 16 < w * h * 3
+        assert rec == sharding.record_bytes(w, h, shards, tw, th) and block == sharding.block_bytes(w, h, shards, tw, th)
+        rng = np.random.default_rng(w)
+        blk = rng.integers(0, 255, block, dtype=np.uint8)
+        one = sharding.make_record(blk, 123456789012)
+        assert one.size == rec and int(one[rec - 8:].view(np.uint64)[0]) == 123456789012 and one[:block].tobytes() == blk.tobytes()
+    bad = r1.make_params(0, 5, 1)
+    assert binding.shard_record_bytes(bad) == 0 and binding.frame_record_bytes(bad) == 0
