@@ -522,6 +522,24 @@ def test_bench_two_ranks_rehearsal_gathers_the_unsharded_frame():
     assert line["value_device_resident"]["value"] > 0
 
 
+def test_bench_rank_path_with_a_one_rank_rccl_communicator():
+    """The rank path of bench.py on the one-GPU box: rank 0's tiles of a 4-GPU run (--emulate-shards 4), frame batches, the
+    per-launch all-gather through a ONE-rank RCCL communicator (--rccl-selftest: torch.distributed backend nccl), records
+    copied to the host.  What an N-GPU rank executes, minus the other ranks."""
+    if KERNEL["variant"] != binding.VARIANT_DEFAULT:
+        pytest.skip("runs the program's own kernel choice: once is enough")
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--emulate-shards", "4", "--rccl-selftest", "--steps", "40", "--warmup", "4",
+                          "--no-cpu-baseline", "--no-extras", "--width", "300", "--height", "200", "--spp", "4"],
+                         capture_output=True, timeout=600, cwd=ROOT, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")})
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    c = line["config"]
+    assert c["emulated_shards"] == 4 and c["frames_per_launch"] == 2 and c["launches_in_flight"] == 10 and int(c["gpu_max_hw_queues"]) == 12
+    assert 0 < c["local_rays_per_step"] == c["rays_per_step"] and line["value"] > 0
+
+
 def test_bench_in_process_multi_mode_one_gpu():
     """bench.py --multi inproc: ONE process drives the GPUs through r1_multi_* (ncclCommInitAll + one ncclAllGather per
     frame); on the one-GPU box that is a one-rank communicator — the whole path, collective included."""
