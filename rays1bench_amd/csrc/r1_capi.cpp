@@ -949,7 +949,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     if (big || (R1_STACK_LDS_WORDS < R1_STACK_WORDS && (variant == 4 || variant == 5)))
     {
         // sized for the largest grid of this kernel (not this frame's): a frame with a bigger grid must not reallocate
-        const size_t entries = big ? R1_STACK_ENTRIES : R1_STACK_ENTRIES - 3 * R1_STACK_LDS_WORDS;
+        const size_t entries = big ? R1_STACK_ENTRIES : R1_STACK_ENTRIES - 3 * R1_STACK_LDS_WORDS_TP; // (sized for the build that keeps the fewest words in LDS)
         const size_t max_blocks = std::max((size_t)blocks, (size_t)c->cus * (size_t)per_cu);
         if ((rc = ensure(c->gstack, entries * max_blocks * R1_BLOCK * 4)))
             return rc;

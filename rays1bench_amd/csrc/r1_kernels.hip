@@ -1181,10 +1181,12 @@ __device__ __forceinline__ bool shade_level(const R1TraceArgs &A, Path &p, const
 // The big-scene tree kernel waits for node fetches from L2, not for the VALU: it is built for 8 waves per SIMD (<= 64 VGPRs,
 // which it meets without the spare sample, and <= 96 SGPRs — at its natural 106 the 800 SGPRs of a SIMD hold seven waves):
 // 13.1 -> 14.4 Grays/s on 100 004 spheres.
-template <int VARIANT, bool STATS, bool BIG>
+// (round 3: the small-scene tree kernels for frames in flight, MODE 0 / 3, run SEVEN workgroups per CU — their LDS footprint is 22 KB with
+// R1_STACK_LDS_WORDS_TP — so they are built for 7 waves per SIMD: <= 73 VGPRs, which the kernel meets at 69, and <= 96 SGPRs)
+template <int VARIANT, bool STATS, bool BIG, int MODE>
 struct TraceWaves
 {
-    static constexpr int value = STATS ? 1 : (VARIANT == 4 ? (BIG ? 8 : 6) : (VARIANT == 2 && !BIG ? 5 : 1));
+    static constexpr int value = STATS ? 1 : (VARIANT == 4 ? (BIG ? 8 : ((MODE == 0 || MODE == 3) ? 7 : 6)) : (VARIANT == 2 && !BIG ? 5 : 1));
 };
 
 // MODE 1 = LAT = latency-mode build (the synchronous entry points: one frame, full grid): sub-queues and
@@ -1193,7 +1195,7 @@ struct TraceWaves
 // MODE 0 = frames in flight (the throughput entry point): samples in one guided queue, few long-lived waves per frame.
 // MODE 2 = PIXEL mode (the throughput entry point after r1_set_pixel_mode; see struct Pixel): the queue holds pixels.
 template <int VARIANT, bool STATS, bool BIG, int MODE>
-__global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::value)) r1_trace_kernel(const R1TraceArgs A)
+__global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MODE>::value)) r1_trace_kernel(const R1TraceArgs A)
 {
     constexpr bool LAT = MODE == 1, PIX = MODE == 2, BATCH = MODE == 3; // MODE 3 = MODE 0 whose queue spans the frames of a batch
     typedef typename IdxType<BIG>::type IDX;
@@ -1213,7 +1215,8 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG>::va
         wave_log = (unsigned long long *)A.stats[15];
         log_start = __builtin_amdgcn_s_memrealtime();
     }
-    constexpr int LW = VARIANT == 4 ? R1_STACK_LDS_WORDS : R1_STACK_WORDS; // words of the attenuation stack in LDS
+    // words of the attenuation stack in LDS (the rest of a deep path's entries live in the global workspace)
+    constexpr int LW = VARIANT == 4 ? (((MODE == 0 || MODE == 3) && !STATS) ? R1_STACK_LDS_WORDS_TP : R1_STACK_LDS_WORDS) : R1_STACK_WORDS;
     __shared__ uint32_t s_stack[BIG ? 1 : LW * R1_BLOCK];
     __shared__ uint32_t s_cand[VARIANT == 2 ? (BIG ? R1_CAND_CAP : R1_BIT_WORDS) * R1_BLOCK : 1];
     __shared__ IDX s_pairs[VARIANT == 2 ? (R1_BLOCK / 64) * PairBits<IDX>::cap : 1];
