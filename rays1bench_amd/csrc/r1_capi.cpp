@@ -855,7 +855,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     const int occ_slot = variant + 8 * big + 16 * mode;
     if (c->occupancy[occ_slot] == 0)
         R1_HIP(r1_trace_occupancy(variant, big, mode,
-                                  (variant == 4 || variant == 5) ? (size_t)a.bvh_depth * R1_BLOCK * 4 + (size_t)a.bvh_lds_f4 * 16 : 0,
+                                  (variant == 4 || variant == 5) ? (size_t)a.bvh_depth * R1_BLOCK * (big ? 4 : 2) + (size_t)a.bvh_lds_f4 * 16 : 0,
                                   &c->occupancy[occ_slot]));
     int per_cu = c->occupancy[occ_slot];
     if (per_cu < 1)

@@ -16,7 +16,7 @@
 #endif                        // the global workspace.  10 KB instead of 17: room for the 128-node table (8 KB) and the traversal stack (8 KB)
                               // at 6 workgroups per CU (27.3 KB each); 4 / 6 / 8 / 10 / 12 words: 28.4 / 29.1 / 29.3 (32.3) / (32.5) / 28.2 Grays/s
 #ifndef R1_STACK_LDS_WORDS_TP
-#define R1_STACK_LDS_WORDS_TP 6 // the same for the THROUGHPUT builds of that kernel (frames in flight, MODE 0 / 3): 6 KB + 8 KB traversal stack + 8 KB node
+#define R1_STACK_LDS_WORDS_TP 10 // the same for the THROUGHPUT builds of that kernel (frames in flight, MODE 0 / 3): 6 KB + 8 KB traversal stack + 8 KB node
 #endif                          // table = 22 KB per workgroup = SEVEN workgroups per CU (23.4 KB each at most), one more wave per SIMD for a kernel that is
                                 // bound by VALU issue at 70 % of its peak: +3 % against the same stack at six, +1.3-2 % net of the deeper global overflow
                                 // (entries 19 and up; 10 words at six workgroups: 32.0, 6 words at six: 31.4, 6 words at seven: 32.4 Grays/s to the host).

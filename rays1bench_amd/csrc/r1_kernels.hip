@@ -666,6 +666,19 @@ __device__ __forceinline__ void leaf_quad(const float4 *__restrict__ prims, cons
     }
 }
 
+// Traversal-stack entries.  Big scenes: the 32-bit child reference as it is.  Small scenes (the kernels that keep the node table in LDS:
+// <= 256 nodes, <= 1023 spheres = 512 pairs): 16 bits — bit 15 leaf, bits 12..14 the pair count, bits 0..11 the node or first pair —
+// which halves the stack in LDS (4 KB instead of 8 for the large scene's tree: together with the 10-word attenuation stack and the
+// node table 22 KB per workgroup = seven workgroups per CU with the whole attenuation stack of round 2 in LDS).
+__device__ __forceinline__ void trav_put(uint32_t *trav, const int at, const uint32_t ref) { trav[at] = ref; }
+__device__ __forceinline__ uint32_t trav_get(const uint32_t *trav, const int at) { return trav[at]; }
+__device__ __forceinline__ void trav_put(uint16_t *trav, const int at, const uint32_t ref) { trav[at] = (uint16_t)(((ref >> 16) & 0xF000u) | (ref & 0x0FFFu)); }
+__device__ __forceinline__ uint32_t trav_get(const uint16_t *trav, const int at)
+{
+    const uint32_t v = trav[at];
+    return ((v & 0xF000u) << 16) | (v & 0x0FFFu);
+}
+
 // Traversal state of one lane.  It lives in registers ACROSS the outer loop of the trace kernel
 // (carry-over, below); the stack entries are in LDS, [entry][thread].
 struct Trav
@@ -695,8 +708,8 @@ __device__ __forceinline__ void trav_start(Trav &t)
 // utilisation of the node / leaf steps 0.53 / 0.69 -> 0.74 / 0.75, and 5 % SLOWER once the node table sat in LDS, because
 // the vote costs ~20 VALU instructions per trip; removed in round 3)
 // LN: the node table is read from `lnodes`, the workgroup's copy in LDS (the trace kernel on small scenes), instead of S.bvh_nodes.
-template <bool STATS, bool CARRY, bool LN>
-__device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, const V3 d, Trav &tv, uint32_t *trav, const int tid,
+template <bool STATS, bool CARRY, bool LN, typename TS>
+__device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, const V3 d, Trav &tv, TS *trav, const int tid,
                                             const uint32_t n_alive, unsigned long long *wstat, const float4 *lnodes /* LDS */, const uint32_t top = 0u /* !LN: nodes [0, top) are in lnodes */)
 {
     const float4 *__restrict__ nodes = S.bvh_nodes;
@@ -755,7 +768,7 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
             if (h0 && h1)
             {
                 const bool swap = tn1 < tn0;
-                trav[sp * R1_BLOCK + tid] = swap ? c0 : c1;
+                trav_put(trav, sp * R1_BLOCK + tid, swap ? c0 : c1);
                 ++sp;
                 cur = swap ? c1 : c0;
             }
@@ -764,7 +777,7 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
             else if (h1)
                 cur = c1;
             else if (sp > 0)
-                cur = trav[--sp * R1_BLOCK + tid];
+                cur = trav_get(trav, --sp * R1_BLOCK + tid);
             else
                 cur = R1_BVH_DONE;
         }
@@ -785,7 +798,7 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
                 }
                 leaf_quad(prims, ids, first + j, take, o, d, best, best_id);
             }
-            cur = sp > 0 ? trav[--sp * R1_BLOCK + tid] : R1_BVH_DONE;
+            cur = sp > 0 ? trav_get(trav, --sp * R1_BLOCK + tid) : R1_BVH_DONE;
         }
     }
     tv.cur = cur, tv.sp = sp, tv.best = best, tv.best_id = best_id;
@@ -800,7 +813,7 @@ __device__ __forceinline__ void sweep_bvh(const R1DeviceScene &S, const bool ali
     trav_start(tv);
     if (!alive)
         tv.cur = R1_BVH_DONE;
-    bvh_advance<STATS, false, false>(S, o, d, tv, trav, tid, 64u, wstat, nullptr);
+    bvh_advance<STATS, false, false, uint32_t>(S, o, d, tv, trav, tid, 64u, wstat, nullptr);
     if (tv.best_id != 0xFFFFFFFFu)
     {
         t_max = tv.best;
@@ -1234,12 +1247,14 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
     // answers sooner than the vector L1, and the table no longer competes with the sphere tables for its 32 KB:
     // 26.9 -> 29.3 Grays/s, one synchronous frame 1.34 -> 1.17 ms (large scene, 128 nodes = 8 KB).
     constexpr bool LN = VARIANT == 4 && !BIG;
-    const float4 *lnodes = (const float4 *)(s_trav + (VARIANT == 4 ? (size_t)A.bvh_depth * R1_BLOCK : 0));
+    typedef typename IdxType<!LN>::type TS; // traversal-stack entry: uint16_t for the small-scene tree kernels, else uint32_t
+    const size_t trav_words = VARIANT == 4 ? (size_t)A.bvh_depth * R1_BLOCK * sizeof(TS) / 4 : 0; // (bvh_depth x 256 entries: a multiple of 16 bytes either way)
+    const float4 *lnodes = (const float4 *)(s_trav + trav_words);
     // (big scenes: A.bvh_lds_f4 covers the first nodes of the breadth-first top of the tree only)
     const uint32_t top = LN ? 0u : A.bvh_lds_f4 >> 2;
     if (VARIANT == 4 && A.bvh_lds_f4)
     {
-        float4 *dst = (float4 *)(s_trav + (size_t)A.bvh_depth * R1_BLOCK);
+        float4 *dst = (float4 *)(s_trav + trav_words);
         for (uint32_t i = (uint32_t)tid; i < A.bvh_lds_f4; i += R1_BLOCK)
             dst[i] = A.scene.bvh_nodes[i];
         __syncthreads();
@@ -1431,7 +1446,7 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
         else if (VARIANT == 4)
         {
             // while-while with carry-over
-            bvh_advance<STATS, true, LN>(A.scene, p.o, p.d, tv, s_trav, tid, (uint32_t)__popcll(live_now), wstat, lnodes, top);
+            bvh_advance<STATS, true, LN, TS>(A.scene, p.o, p.d, tv, (TS *)s_trav, tid, (uint32_t)__popcll(live_now), wstat, lnodes, top);
             ready = alive && tv.cur == R1_BVH_DONE;
             if (tv.best_id != 0xFFFFFFFFu)
                 t_hit = tv.best, hit = (int)tv.best_id;
@@ -1765,8 +1780,8 @@ extern "C" int r1_trace_mode(int variant, int big, int wanted)
 extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int big_in, int mode, int blocks, hipStream_t stream)
 {
     // dynamic LDS of the tree kernels: the traversal stack, one entry per inner node on a path, and (small scenes) the node table
-    const size_t trav = ((variant == 4 || variant == 5) ? (size_t)args->bvh_depth * R1_BLOCK * sizeof(uint32_t) + (size_t)args->bvh_lds_f4 * 16 : 0);
     const bool big = big_in != 0; // 32-bit hit indices, attenuation stack in the global workspace
+    const size_t trav = ((variant == 4 || variant == 5) ? (size_t)args->bvh_depth * R1_BLOCK * (big ? sizeof(uint32_t) : sizeof(uint16_t)) + (size_t)args->bvh_lds_f4 * 16 : 0);
 #define R1_GO(V, S, B, M) hipLaunchKernelGGL((r1_trace_kernel<V, S, B, M>), dim3(blocks), dim3(R1_BLOCK), (V) == 4 ? trav : 0, stream, *args)
     if (mode != r1_trace_mode(variant, big_in, mode))
         return hipErrorInvalidValue; // the caller sizes its arguments by the mode: it must be the one that is built
