@@ -1199,7 +1199,10 @@ __device__ __forceinline__ bool shade_level(const R1TraceArgs &A, Path &p, const
 template <int VARIANT, bool STATS, bool BIG, int MODE>
 struct TraceWaves
 {
-    static constexpr int value = STATS ? 1 : (VARIANT == 4 ? (BIG ? 8 : ((MODE == 0 || MODE == 3) ? 7 : 6)) : (VARIANT == 2 && !BIG ? 5 : 1));
+#ifndef R1_TREE_WAVES_TP
+#define R1_TREE_WAVES_TP 7
+#endif
+    static constexpr int value = STATS ? 1 : (VARIANT == 4 ? (BIG ? 8 : ((MODE == 0 || MODE == 3) ? R1_TREE_WAVES_TP : 6)) : (VARIANT == 2 && !BIG ? 5 : 1));
 };
 
 // MODE 1 = LAT = latency-mode build (the synchronous entry points: one frame, full grid): sub-queues and
