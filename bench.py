@@ -404,6 +404,8 @@ def run_ranks(args):
         B = 1           # PIXEL mode has no batch form
     frec = binding.frame_record_bytes(p)  # image (padded to 8 bytes) + uint64 ray count
 
+    submit_max = {"render": 0.0, "gather": 0.0, "assemble": 0.0, "copy": 0.0}
+
     class Slot:
         """One launch in flight: its own context (stream-ordered workspace), stream, device buffers and page-locked host
         frames.  step() adds a frame to the slot's pending batch; the batch is launched when it is full (or at a fence)."""
@@ -445,21 +447,30 @@ def run_ranks(args):
                     self.rend.render_batch_async(p, k, self.host if host_copy[0] else None, 0, sp)
                 return
             with torch.cuda.stream(self.stream):
+                t_ = [time.perf_counter()]
                 if args.pixel_mode:
                     self.rend.render_shard_device(p, self.records.data_ptr(), self.records.data_ptr() + trailer, sp)
                 else:
                     self.rend.render_shard_device_batch(p, k, self.records.data_ptr(), 0, sp)
+                t_.append(time.perf_counter())
                 if n > 1:  # the one exchange step of the batch: [rank][frame][record]
                     sharding.gather_records(dist, self.records[:k * record_bytes], self.gathered[:n * k * record_bytes])
                 elif args.rccl_selftest:
                     dist.all_gather_into_tensor(self.selftest[:k * record_bytes], self.records[:k * record_bytes])
+                t_.append(time.perf_counter())
                 if n > 1 or not sharded:
                     self.rend.assemble_device_records_batch(p, k, self.gathered.data_ptr(), self.frames.data_ptr(), sp)
+                    t_.append(time.perf_counter())
                     if host_copy[0]:
                         self.host_t[:k * frec].copy_(self.frames[:k * frec], non_blocking=True)
-                elif host_copy[0]:
-                    # emulated rank of a K-GPU run: its own records stand in for the gathered frames (same bytes per frame / K)
-                    self.host_t[:k * record_bytes].copy_(self.records[:k * record_bytes], non_blocking=True)
+                else:
+                    t_.append(time.perf_counter())
+                    if host_copy[0]:
+                        # emulated rank of a K-GPU run: its own records stand in for the gathered frames (same bytes per frame / K)
+                        self.host_t[:k * record_bytes].copy_(self.records[:k * record_bytes], non_blocking=True)
+                t_.append(time.perf_counter())
+                for i_, name in enumerate(("render", "gather", "assemble", "copy")):  # slowest submission of each kind (host time)
+                    submit_max[name] = max(submit_max[name], (t_[i_ + 1] - t_[i_]) * 1e3)
 
         def frame_rays(self):
             """Whole-frame ray count of the slot's last launch as it landed (host) or as the device holds it."""
@@ -551,7 +562,10 @@ def run_ranks(args):
     if sharded and n == 1:
         rays_per_step = slots[0].local_rays()  # emulated rank: its share only
 
+    for k_ in submit_max:
+        submit_max[k_] = 0.0
     elapsed, submit, (trace_ms_sum, total_ms_sum, launches) = timed(args.steps, with_events=True)
+    submit_max_timed = dict(submit_max)
     frames = args.steps
     value = rays_per_step * args.steps / elapsed / 1e6
     info = rend.launch_info()
@@ -692,6 +706,7 @@ def run_ranks(args):
             "frames_in_flight": len(slots) * B, "launches_in_flight": len(slots), "frames_per_launch": B,
             "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
             "host_submit_ms_per_step": submit / args.steps * 1e3, "setup_passes": setup_passes,
+            "slowest_submission_ms": submit_max_timed if (sharded or args.pixel_mode) else None,
             "kernel": kernel_name})
         if is_tree:
             cfg["bvh"] = {"nodes": info["bvh_nodes"], "leaves": info["bvh_leaves"], "depth": info["bvh_depth"]}
