@@ -13,14 +13,12 @@
 #define R1_STACK_WORDS 17   // ceil(51 / 3) packed 10-bit hit indices per lane (max_bounces <= 51)
 #ifndef R1_STACK_LDS_WORDS
 #define R1_STACK_LDS_WORDS 10 // tree kernel, small scenes: words of the packed stack kept in LDS (30 entries); deeper entries (rare) go to
-#endif                        // the global workspace.  10 KB instead of 17: room for the 128-node table (8 KB) and the traversal stack (8 KB)
-                              // at 6 workgroups per CU (27.3 KB each); 4 / 6 / 8 / 10 / 12 words: 28.4 / 29.1 / 29.3 (32.3) / (32.5) / 28.2 Grays/s
+#endif                        // the global workspace.  10 KB instead of 17: with the 128-node table (8 KB) and the 16-bit traversal stack (4 KB,
+                              // round 3) a workgroup holds 22 KB = SEVEN workgroups per CU (23.4 KB each at most; six with round 2's 32-bit
+                              // traversal stack); 4 / 6 / 8 / 10 / 12 words at six workgroups: 28.4 / 29.1 / 29.3 (32.3) / (32.5) / 28.2 Grays/s
 #ifndef R1_STACK_LDS_WORDS_TP
-#define R1_STACK_LDS_WORDS_TP 10 // the same for the THROUGHPUT builds of that kernel (frames in flight, MODE 0 / 3): 6 KB + 8 KB traversal stack + 8 KB node
-#endif                          // table = 22 KB per workgroup = SEVEN workgroups per CU (23.4 KB each at most), one more wave per SIMD for a kernel that is
-                                // bound by VALU issue at 70 % of its peak: +3 % against the same stack at six, +1.3-2 % net of the deeper global overflow
-                                // (entries 19 and up; 10 words at six workgroups: 32.0, 6 words at six: 31.4, 6 words at seven: 32.4 Grays/s to the host).
-                                // The synchronous-frame kernel stays at 10 words and six workgroups (1.155 against 1.177 ms per frame).
+#define R1_STACK_LDS_WORDS_TP 10 // the same for the THROUGHPUT builds of that kernel (MODE 0 / 3), kept apart for experiments: 6 words with the 32-bit
+#endif                           // traversal stack was the first way to seven workgroups (+3 % from the wave, -1.7 % from the deeper global overflow)
 #define R1_NODES_LDS_MAX 256  // tree kernel: scenes whose tree has at most this many nodes (16 KB) run the small-scene kernels, which keep
                               // the node table in LDS; bigger trees run the big-scene kernels (node table through the vector L1)
 #define R1_CHUNK 256        // most samples a wave takes from the global queue per atomic (small frames) ...
