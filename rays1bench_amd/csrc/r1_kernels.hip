@@ -672,12 +672,11 @@ __device__ __forceinline__ void leaf_quad(const float4 *__restrict__ prims, cons
 // node table 22 KB per workgroup = seven workgroups per CU with the whole attenuation stack of round 2 in LDS).
 __device__ __forceinline__ void trav_put(uint32_t *trav, const int at, const uint32_t ref) { trav[at] = ref; }
 __device__ __forceinline__ uint32_t trav_get(const uint32_t *trav, const int at) { return trav[at]; }
-__device__ __forceinline__ void trav_put(uint16_t *trav, const int at, const uint32_t ref) { trav[at] = (uint16_t)(((ref >> 16) & 0xF000u) | (ref & 0x0FFFu)); }
-__device__ __forceinline__ uint32_t trav_get(const uint16_t *trav, const int at)
-{
-    const uint32_t v = trav[at];
-    return ((v & 0xF000u) << 16) | (v & 0x0FFFu);
-}
+// (the small-scene kernels walk with the 16-bit form throughout: the child references are converted once, when the workgroup copies
+// the node table into LDS — r1_ref16 — so a push is a 16-bit store and a pop a zero-extending load)
+__device__ __forceinline__ void trav_put(uint16_t *trav, const int at, const uint32_t ref) { trav[at] = (uint16_t)ref; }
+__device__ __forceinline__ uint32_t trav_get(const uint16_t *trav, const int at) { return trav[at]; }
+__device__ __forceinline__ uint32_t r1_ref16(const uint32_t ref) { return ((ref >> 16) & 0xF000u) | (ref & 0x0FFFu); }
 
 // Traversal state of one lane.  It lives in registers ACROSS the outer loop of the trace kernel
 // (carry-over, below); the stack entries are in LDS, [entry][thread].
@@ -726,6 +725,10 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
     uint32_t best_id = tv.best_id;
     uint32_t cur = tv.cur;
     int sp = tv.sp;
+    // child references: bit 31 leaf / bits 28..30 pair count / 28 bits of index — or, in the LDS copy of a small scene's table,
+    // bit 15 / bits 12..14 / 12 bits (see trav_put)
+    constexpr uint32_t LEAF_BIT = LN ? 0x8000u : 0x80000000u, INDEX_MASK = LN ? 0x0FFFu : 0x0FFFFFFFu;
+    constexpr int COUNT_SHIFT = LN ? 12 : 28;
     for (;;)
     {
         const unsigned long long walking = __ballot(cur != R1_BVH_DONE);
@@ -734,7 +737,7 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
         if (CARRY && R1_CARRY_DIV * (uint32_t)__popcll(walking) <= n_alive)
             break; // (n_alive <= 3: never true while a lane walks, so the last walks of a wave run to their end)
         // inner nodes: descend to the nearer child, remember the farther one
-        while (!(cur & 0x80000000u))
+        while (!(cur & LEAF_BIT))
         {
             if (STATS)
             {
@@ -785,7 +788,7 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
         {
             // leaf: `cnt` PAIRS of spheres {cx_a cx_b cy_a cy_b} {cz_a cz_b rsq_a rsq_b}; an odd
             // sphere's partner has radius_sq = -inf (discriminant -inf: never offers a hit)
-            const uint32_t first = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
+            const uint32_t first = cur & INDEX_MASK, cnt = (cur >> COUNT_SHIFT) & 7u;
             for (uint32_t j = 0; j < cnt; j += 2u)
             {
                 const uint32_t take = cnt - j < 2u ? 1u : 2u;
@@ -1259,7 +1262,12 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
     {
         float4 *dst = (float4 *)(s_trav + trav_words);
         for (uint32_t i = (uint32_t)tid; i < A.bvh_lds_f4; i += R1_BLOCK)
-            dst[i] = A.scene.bvh_nodes[i];
+        {
+            float4 q = A.scene.bvh_nodes[i];
+            if (LN && (i & 3u) == 3u) // {A K child0 child1}: the small-scene kernels walk with 16-bit child references
+                q.z = __uint_as_float(r1_ref16(__float_as_uint(q.z))), q.w = __uint_as_float(r1_ref16(__float_as_uint(q.w)));
+            dst[i] = q;
+        }
         __syncthreads();
     }
 
