@@ -374,9 +374,14 @@ def test_frame_batches_equal_single_frames(renderer):
     for f in range(nf):
         assert frames[f, :w * h * 3].cpu().numpy().tobytes() == want2[f][0].tobytes(), f
         assert int(frames[f, frec - 8:].view(torch.int64).item()) == want2[f][1], f
-    # variants without a throughput kernel refuse batches
+    # variants without a throughput kernel refuse batches; a batch beyond 2^31 sample slots per launch is a documented limit
     with pytest.raises(r1.R1Error):
         renderer.render_batch_async(mp(w, h, spp, 1, variant=binding.VARIANT_REFERENCE), 2, None)
+    with pytest.raises(r1.R1Error) as e:
+        renderer.render_batch_async(mp(1024, 1024, 1000, 1), 3, None)  # 3 x 1.05 G slots
+    assert e.value.code == binding.R1_ELIMIT
+    img_after, rays_after, _ = renderer.render(mp(w, h, spp, 40))  # the context is still usable
+    assert rays_after == want[0][1] and img_after.tobytes() == want[0][0].tobytes()
 
 
 # ---- big scenes (BASELINE config 5 shape: the large generator scaled up) -------------------------
