@@ -272,10 +272,12 @@ def workload_config(args, info, n, rays_per_step):
 
 def run_inproc(args):
     """ONE process, N GPUs: r1_multi_* — tile split, ncclCommInitAll, one ncclAllGather per frame, device 0 assembles and
-    copies to the host (csrc/r1_multi.cpp; rayweek1.cpp:869-877: one call renders on all workers).  One synchronous
-    frame per step, so this mode shows the latency-mode number, never the frames-in-flight one."""
+    copies to the host (csrc/r1_multi.cpp; rayweek1.cpp:869-877: one call renders on all workers).  Frames in flight: K
+    r1_multi objects (each with its own communicator and streams), r1_multi_render_async; `--inflight 1` = the synchronous
+    r1_multi_render, one frame at a time (what rayweek1_hip --gather rccl does inside benchmark())."""
     n = args.gpus
-    set_hw_queues(args, 4)
+    lanes = args.inflight if args.inflight > 0 else 8  # (8 / 12 / 16 / 20 in flight: 32.3 / 31.8 / 31.9 / 31.9 Grays/s on one GPU, profiles/r03/inproc_lanes.txt)
+    set_hw_queues(args, lanes + 1 if lanes > 1 else 4)  # one hardware queue per frame in flight + one (torch's null stream); lanes + 2 is WORSE (mapping)
     import numpy as np
     import torch  # only for the contract's synchronize; r1_multi brings its own RCCL binding
     import rays1bench_amd as r1
@@ -289,53 +291,83 @@ def run_inproc(args):
     w, h, spp = args.width, args.height, args.spp
     gw, gh = (int(v) for v in args.grid.split("x")) if args.scene == "grid" else (0, 0)
     scene = r1.Scene(SCENE_KIND[args.scene], w, h, gw, gh)
-    multi = binding.MultiRenderer(list(range(n)))
-    multi.set_scene(scene)
+    multis = [binding.MultiRenderer(list(range(n))) for _ in range(lanes)]
+    for m_ in multis:
+        m_.set_scene(scene)
+    hosts = [binding.HostFrames(w, h, 1) for _ in range(lanes)]
     p = r1.make_params(w, h, spp, args.seed, variant=args.variant)
     img = np.zeros((h, w, 3), np.uint8)
+    counter = [0]
+    dev_s = [0.0]
 
     def step():
-        return multi.render_into(p, img)
+        k = counter[0] % lanes
+        counter[0] += 1
+        if lanes == 1:
+            rays, s = multis[0].render_into(p, img)
+            dev_s[0] += s
+            return rays
+        multis[k].render_async(p, hosts[k])
+        return None
 
     def fence():
+        for m_ in multis:
+            m_.sync()
         for d in range(n):
             torch.cuda.synchronize(d)
 
-    for _ in range(max(args.warmup, 1)):
-        rays_per_step, _ = step()
+    for _ in range(2):  # setup: buffers, communicators, hardware queues
+        for _ in range(lanes):
+            step()
+        fence()
+    for _ in range(args.warmup):
+        step()
     fence()
+    dev_s[0] = 0.0
     t0 = time.perf_counter()
-    dev_s = 0.0
     for _ in range(args.steps):
-        rays, s = step()
-        dev_s += s
+        step()
+    submit = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
-    info = multi.info()
+    if lanes > 1:
+        rays_per_step = hosts[0].rays(0)
+        img = hosts[0].image(0).copy()
+    else:
+        rays_per_step, _ = multis[0].render_into(p, img)
+    info = multis[0].info()
     check = None
     if args.check:
         rend = r1.Renderer(0)
         rend.set_scene(scene)
         ref = np.zeros((h, w, 3), np.uint8)
         ref_rays, _ = rend.render_into(r1.make_params(w, h, spp, args.seed, variant=args.variant), ref)
-        check = bool(ref.tobytes() == img.tobytes() and ref_rays == rays)
+        check = bool(ref.tobytes() == img.tobytes() and ref_rays == rays_per_step
+                     and all(hf.rays(0) == ref_rays and hf.image(0).tobytes() == ref.tobytes() for hf in hosts[:min(lanes, args.steps)] if lanes > 1))
         rend.close()
     cfg = workload_config(args, info["first_device"], n, rays_per_step)
     cfg.update({"parallelism": f"tile-split x{n}, ONE process (r1_multi: ncclCommInitAll, one ncclAllGather per frame, RCCL {info['rccl_version']})",
-                "value_mode": "one synchronous frame at a time through r1_multi_render: dispatch -> pixels + ray count on the host "
+                "value_mode": (f"{lanes} frames in flight = {lanes} r1_multi objects (own communicator + streams each), r1_multi_render_async: every frame "
+                               "ends with its pixels + ray count copied to page-locked HOST memory by device 0 (rayweek1.cpp:848 -> :891, pipelined)")
+                              if lanes > 1 else
+                              "one synchronous frame at a time through r1_multi_render: dispatch -> pixels + ray count on the host "
                               "(rayweek1.cpp:848 -> :891); latency-mode kernels, no frames in flight",
-                "frames_in_flight": 1, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                "frames_in_flight": lanes, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "workgroups": info["first_device"]["blocks"], "threads_per_workgroup": info["first_device"]["threads_per_block"],
-                "device_ms_per_step": dev_s / args.steps * 1e3})
+                "host_submit_ms_per_step": submit / args.steps * 1e3,
+                "device_ms_per_step": dev_s[0] / args.steps * 1e3 if lanes == 1 else None})
     out = {"metric": f"mrays/s on '{args.scene}' scene {w}x{h}x{spp}spp", "value": rays_per_step * args.steps / elapsed / 1e6, "unit": "mrays/s",
            "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": cfg,
            "roofline": {"bound": "valu", "peak": FP32_VECTOR_PEAK_TF, "unit": "TFLOP/s", "achieved": None, "frac": None, "traffic": None,
-                        "note": "the in-process mode reports the latency of the N-GPU frame; the kernel's roofline is measured by the default mode"}}
+                        "note": "the in-process mode reports the rate of the N-GPU frames; the kernel's roofline is measured by the default mode"}}
     if check is not None:
         out["check"] = check
     print(json.dumps(out), flush=True)
-    multi.close()
+    for m_ in multis:
+        m_.close()
+    for hf in hosts:
+        hf.close()
     return 0
 
 

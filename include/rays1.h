@@ -319,6 +319,12 @@ int r1_multi_set_scene(r1_multi *m, const r1_scene *scene, const r1_camera *came
 /* rgb_out / num_rays_out as r1_render (whole frame); device_seconds_out (optional): render + gather
  * on the slowest device, from HIP events. */
 int r1_multi_render(r1_multi *m, const r1_params *params, uint8_t *rgb_out, uint64_t *num_rays_out, double *device_seconds_out);
+/* Frames in flight across the N GPUs from one process: the enqueue-only form of r1_multi_render (throughput kernels, this
+ * object's own all-gather, device 0 assembles image + summed count into ONE frame record — r1_frame_record_bytes() — and copies
+ * it into `host_frame`, page-locked memory).  Nothing is waited for; r1_multi_sync waits for this object's frame.  A caller
+ * keeps K frames in flight with K r1_multi objects (each owns a communicator), as K r1_contexts do on one GPU. */
+int r1_multi_render_async(r1_multi *m, const r1_params *params, void *host_frame);
+int r1_multi_sync(r1_multi *m);
 /* Facts for reports: device count, RCCL version code (ncclGetVersion), launch info of the first device. */
 int r1_multi_info(r1_multi *m, int32_t *n_devices, int32_t *rccl_version, r1_launch_info *first_device);
 

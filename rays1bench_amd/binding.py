@@ -113,6 +113,8 @@ SYMBOLS = [
     ("r1_multi_destroy", None, [C.c_void_p]),
     ("r1_multi_set_scene", C.c_int, [C.c_void_p, C.POINTER(CScene), C.POINTER(CCamera)]),
     ("r1_multi_render", C.c_int, [C.c_void_p, C.POINTER(Params), _u8p, _u64p, _dblp]),
+    ("r1_multi_render_async", C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p]),
+    ("r1_multi_sync", C.c_int, [C.c_void_p]),
     ("r1_multi_info", C.c_int, [C.c_void_p, _i32p, _i32p, C.POINTER(LaunchInfo)]),
     ("r1_assemble_device", C.c_int, [_ctx, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p]),
     ("r1_assemble_device_strided", C.c_int, [_ctx, C.POINTER(Params), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
@@ -436,6 +438,13 @@ class MultiRenderer:
         rays, secs = C.c_uint64(), C.c_double()
         _check(lib().r1_multi_render(self._m, C.byref(params), img.ctypes.data_as(_u8p), C.byref(rays), C.byref(secs)))
         return int(rays.value), float(secs.value)
+
+    def render_async(self, params, host_frames):
+        """r1_multi_render_async: enqueue one frame over the N GPUs; its record lands in `host_frames` (a HostFrames of 1)."""
+        _check(lib().r1_multi_render_async(self._m, C.byref(params), C.c_void_p(host_frames.ptr)))
+
+    def sync(self):
+        _check(lib().r1_multi_sync(self._m))
 
     def info(self):
         n, v, li = C.c_int32(), C.c_int32(), LaunchInfo()

@@ -230,6 +230,10 @@ extern "C" int r1_create(int device, r1_context **out)
     return R1_OK;
 }
 
+// internal (r1_multi.cpp): the context's own stream, so that the in-process multi-GPU path runs its collectives on the stream the
+// context's uploads and frames already use instead of a second stream per device (every stream wants a hardware queue)
+extern "C" void *r1_context_stream(r1_context *c) { return c ? (void *)c->stream : nullptr; }
+
 extern "C" void r1_destroy(r1_context *c)
 {
     if (!c)

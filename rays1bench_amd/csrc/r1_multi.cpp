@@ -24,6 +24,7 @@
 #include "../../include/rays1.h"
 
 extern "C" void r1_set_error(const char *fmt, ...);
+extern "C" void *r1_context_stream(r1_context *c); // r1_capi.cpp (internal): the context's own stream
 
 namespace
 {
@@ -135,8 +136,7 @@ extern "C" void r1_multi_destroy(r1_multi *m)
             (void)hipEventDestroy(m->ev0[i]);
         if (i < (int)m->ev1.size() && m->ev1[i])
             (void)hipEventDestroy(m->ev1[i]);
-        if (i < (int)m->stream.size() && m->stream[i])
-            (void)hipStreamDestroy(m->stream[i]);
+        // (m->stream[i] is the context's own stream: destroyed with the context)
         r1_destroy(m->ctx[i]);
     }
     // the library handle stays open: other communicators of the process may live in it
@@ -204,7 +204,8 @@ extern "C" int r1_multi_create(int32_t n_devices, const int32_t *devices, r1_mul
         return fail(rc);
     for (int i = 0; i < n_devices; ++i)
     {
-        if (hipSetDevice(m->device[i]) != hipSuccess || hipStreamCreateWithFlags(&m->stream[i], hipStreamNonBlocking) != hipSuccess ||
+        m->stream[i] = (hipStream_t)r1_context_stream(m->ctx[i]); // one stream per device: the context's own
+        if (hipSetDevice(m->device[i]) != hipSuccess || !m->stream[i] ||
             hipEventCreate(&m->ev0[i]) != hipSuccess || hipEventCreate(&m->ev1[i]) != hipSuccess)
         {
             r1_set_error("r1_multi_create: stream/event creation failed on device %d", m->device[i]);
@@ -234,21 +235,9 @@ extern "C" int r1_multi_set_scene(r1_multi *m, const r1_scene *scene, const r1_c
     return R1_OK;
 }
 
-extern "C" int r1_multi_render(r1_multi *m, const r1_params *params, uint8_t *rgb_out, uint64_t *num_rays_out, double *device_seconds_out)
+// device buffers of one r1_multi: every device's record + gathered records, device 0's image (or frame record)
+static int multi_buffers(r1_multi *m, const size_t record, const size_t rgb_bytes)
 {
-    if (!m || !params || !rgb_out)
-    {
-        r1_set_error("r1_multi_render: null argument");
-        return R1_EINVAL;
-    }
-    r1_params p = *params;
-    p.shard = 0, p.num_shards = m->n;
-    const size_t block = r1_shard_block_bytes(&p);
-    if (block == 0)
-        return R1_EINVAL;
-    const size_t record = r1_shard_record_bytes(&p); // block, padded to 8 bytes, + the shard's uint64 ray count: pixels and counts travel in one collective
-    const size_t trailer = record - 8;
-    const size_t rgb_bytes = (size_t)p.width * p.height * 3;
     if (record > m->record_cap)
     {
         for (int i = 0; i < m->n; ++i)
@@ -274,6 +263,29 @@ extern "C" int r1_multi_render(r1_multi *m, const r1_params *params, uint8_t *rg
         m->d_rgb = nullptr;
         R1M_HIP(hipMalloc(&m->d_rgb, rgb_bytes));
         m->rgb_cap = rgb_bytes;
+    }
+    return R1_OK;
+}
+
+extern "C" int r1_multi_render(r1_multi *m, const r1_params *params, uint8_t *rgb_out, uint64_t *num_rays_out, double *device_seconds_out)
+{
+    if (!m || !params || !rgb_out)
+    {
+        r1_set_error("r1_multi_render: null argument");
+        return R1_EINVAL;
+    }
+    r1_params p = *params;
+    p.shard = 0, p.num_shards = m->n;
+    const size_t block = r1_shard_block_bytes(&p);
+    if (block == 0)
+        return R1_EINVAL;
+    const size_t record = r1_shard_record_bytes(&p); // block, padded to 8 bytes, + the shard's uint64 ray count: pixels and counts travel in one collective
+    const size_t trailer = record - 8;
+    const size_t rgb_bytes = (size_t)p.width * p.height * 3;
+    {
+        const int rc_buf = multi_buffers(m, record, rgb_bytes);
+        if (rc_buf != R1_OK)
+            return rc_buf;
     }
     // 1. every device traces + resolves its tiles into its record (latency-mode kernels: one frame, the caller waits)
     // From the first enqueue on, a failure must not leave work in flight behind the caller's back: the error is
@@ -373,6 +385,85 @@ extern "C" int r1_multi_render(r1_multi *m, const r1_params *params, uint8_t *rg
             worst = ms > worst ? ms : worst;
         }
         *device_seconds_out = worst * 1e-3; // render + gather, slowest device
+    }
+    return R1_OK;
+}
+
+// Frames in flight across N GPUs from ONE process: the enqueue-only form of r1_multi_render.  Every device renders its tiles with
+// the THROUGHPUT kernels (few long-lived waves per frame), the records go through this r1_multi's own all-gather, device 0 assembles
+// image + summed ray count into one frame record and copies it into `host_frame` (r1_frame_record_bytes, page-locked) — all on the
+// object's streams, nothing is waited for.  A caller keeps K frames in flight with K r1_multi objects (each has its own communicator:
+// collectives of different frames never share one), exactly as K r1_contexts do on one GPU; r1_multi_sync waits for this object's frame.
+extern "C" int r1_multi_render_async(r1_multi *m, const r1_params *params, void *host_frame)
+{
+    if (!m || !params || !host_frame)
+    {
+        r1_set_error("r1_multi_render_async: null argument");
+        return R1_EINVAL;
+    }
+    r1_params p = *params;
+    p.shard = 0, p.num_shards = m->n;
+    const size_t record = r1_shard_record_bytes(&p), frame = r1_frame_record_bytes(&p);
+    if (record == 0 || frame == 0)
+        return R1_EINVAL;
+    {
+        const int rc_buf = multi_buffers(m, record, frame);
+        if (rc_buf != R1_OK)
+            return rc_buf;
+    }
+    auto drain = [&](int rc) {
+        for (int i = 0; i < m->n; ++i)
+            if (hipSetDevice(m->device[i]) == hipSuccess)
+                (void)hipStreamSynchronize(m->stream[i]);
+        return rc;
+    };
+    int rc = R1_OK;
+    for (int i = 0; i < m->n && rc == R1_OK; ++i)
+    {
+        r1_params q = p;
+        q.shard = i;
+        if (hipSetDevice(m->device[i]) != hipSuccess)
+        {
+            r1_set_error("r1_multi_render_async: cannot select device %d", m->device[i]);
+            rc = R1_EHIP;
+            break;
+        }
+        rc = r1_render_shard_device(m->ctx[i], &q, m->d_record[i], (char *)m->d_record[i] + record - 8, m->stream[i]);
+    }
+    if (rc != R1_OK)
+        return drain(rc);
+    ncclResult_t nr = m->rccl.GroupStart();
+    if (nr != 0)
+    {
+        r1_set_error("ncclGroupStart failed: %s", m->rccl.GetErrorString(nr));
+        return drain(R1_EHIP);
+    }
+    for (int i = 0; i < m->n && nr == 0; ++i)
+        nr = m->rccl.AllGather(m->d_record[i], m->d_gathered[i], record, R1_NCCL_UINT8, m->comm[i], m->stream[i]);
+    const ncclResult_t ne = m->rccl.GroupEnd();
+    if (nr != 0 || ne != 0)
+    {
+        r1_set_error("ncclAllGather of the frame's records failed: %s", m->rccl.GetErrorString(nr != 0 ? nr : ne));
+        return drain(R1_EHIP);
+    }
+    hipError_t he = hipSetDevice(m->device[0]);
+    rc = he == hipSuccess ? r1_assemble_device_records(m->ctx[0], &p, m->d_gathered[0], m->d_rgb, (char *)m->d_rgb + frame - 8, m->stream[0]) : R1_EHIP;
+    if (rc == R1_OK && hipMemcpyAsync(host_frame, m->d_rgb, frame, hipMemcpyDeviceToHost, m->stream[0]) != hipSuccess)
+    {
+        r1_set_error("r1_multi_render_async: copy to the host failed");
+        rc = R1_EHIP;
+    }
+    return rc == R1_OK ? R1_OK : drain(rc);
+}
+
+extern "C" int r1_multi_sync(r1_multi *m)
+{
+    if (!m)
+        return R1_EINVAL;
+    for (int i = 0; i < m->n; ++i)
+    {
+        R1M_HIP(hipSetDevice(m->device[i]));
+        R1M_HIP(hipStreamSynchronize(m->stream[i]));
     }
     return R1_OK;
 }

@@ -552,12 +552,13 @@ def test_bench_in_process_multi_mode_one_gpu():
         pytest.skip("runs the program's own kernel choice: once is enough")
     import subprocess
     import sys
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--multi", "inproc", "--steps", "5", "--warmup", "2",
-                          "--check", "--width", "300", "--height", "200", "--spp", "4"], capture_output=True, timeout=600, cwd=ROOT)
-    assert out.returncode == 0, out.stderr.decode()[-2000:]
-    line = json.loads(out.stdout.decode().strip().splitlines()[-1])
-    assert line["check"] is True and line["n_gpus"] == 1 and "r1_multi" in line["config"]["parallelism"]
-    assert line["value"] > 0 and abs(line["value"] - line["config"]["rays_per_step"] / line["ms_per_step"] / 1e3) < 1e-6 * line["value"]
+    for inflight, mode in (("1", "one synchronous frame"), ("4", "4 frames in flight")):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--multi", "inproc", "--steps", "9", "--warmup", "2",
+                              "--inflight", inflight, "--check", "--width", "300", "--height", "200", "--spp", "4"], capture_output=True, timeout=600, cwd=ROOT)
+        assert out.returncode == 0, out.stderr.decode()[-2000:]
+        line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+        assert line["check"] is True and line["n_gpus"] == 1 and "r1_multi" in line["config"]["parallelism"] and mode in line["config"]["value_mode"]
+        assert line["value"] > 0 and abs(line["value"] - line["config"]["rays_per_step"] / line["ms_per_step"] / 1e3) < 1e-6 * line["value"]
 
 
 # ---- sphere-count edges: empty scene, last small-kernel scene, first big-kernel scene ------------
