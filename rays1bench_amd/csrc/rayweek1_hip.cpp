@@ -317,6 +317,7 @@ static void log_json(const char *version, const char *scene, const RESULT *resul
 static int pipelined(const char *scene_name, int kind, int frames)
 {
     const int k = g_inflight < frames ? g_inflight : frames;
+    const bool multi = g_gather == 1 && g_devices >= 1 && g_multi; // --gather rccl: every frame in flight is split over the N devices (r1_multi)
     r1_host_scene *hs = nullptr;
     if (r1_host_scene_create(kind, g_screen_w, g_screen_h, 0, 0, &hs) != R1_OK)
         return 1;
@@ -324,19 +325,28 @@ static int pipelined(const char *scene_name, int kind, int frames)
     memset(&p, 0, sizeof(p));
     p.width = g_screen_w, p.height = g_screen_h, p.spp = g_spp, p.max_bounces = g_max_bounces, p.seed = g_seed;
     p.tile_w = 32, p.tile_h = 32, p.shard = 0, p.num_shards = 1, p.variant = g_variant;
-    const size_t img = (size_t)g_screen_w * g_screen_h * 3, rec = ((img + 7) & ~(size_t)7) + 8;
+    const size_t rec = r1_frame_record_bytes(&p); // image, padded to 8 bytes, + uint64 ray count
     std::vector<r1_context *> ctx((size_t)k, nullptr);
+    std::vector<r1_multi *> mul((size_t)k, nullptr);
     std::vector<uint8_t *> host((size_t)k, nullptr);
     int rc = R1_OK;
     const int visible = r1_device_count();
+    std::vector<int32_t> devs;
+    for (int i = 0; i < g_devices; ++i)
+        devs.push_back(g_device + i);
     for (int i = 0; i < k && rc == R1_OK; ++i) // every context first, the scenes afterwards: the streams get their own hardware queues
-        rc = r1_create(g_device % (visible > 0 ? visible : 1), &ctx[(size_t)i]);
+        rc = multi ? r1_multi_create(g_devices, devs.data(), &mul[(size_t)i]) : r1_create(g_device % (visible > 0 ? visible : 1), &ctx[(size_t)i]);
     for (int i = 0; i < k && rc == R1_OK; ++i)
     {
-        rc = r1_set_scene(ctx[(size_t)i], r1_host_scene_spheres(hs), r1_host_scene_camera(hs));
+        rc = multi ? r1_multi_set_scene(mul[(size_t)i], r1_host_scene_spheres(hs), r1_host_scene_camera(hs))
+                   : r1_set_scene(ctx[(size_t)i], r1_host_scene_spheres(hs), r1_host_scene_camera(hs));
         if (rc == R1_OK)
             rc = r1_host_alloc(rec, (void **)&host[(size_t)i]);
     }
+    auto enqueue = [&](size_t s) {
+        return multi ? r1_multi_render_async(mul[s], &p, host[s]) : r1_render_async(ctx[s], &p, host[s], (uint64_t *)(host[s] + rec - 8), nullptr);
+    };
+    auto wait = [&](size_t s) { return multi ? r1_multi_sync(mul[s]) : r1_sync(ctx[s]); };
     uint64_t rays = 0;
     double secs = 0;
     if (rc == R1_OK)
@@ -344,36 +354,38 @@ static int pipelined(const char *scene_name, int kind, int frames)
         for (int pass = 0; pass < 2 && rc == R1_OK; ++pass) // pass 0: workspaces and queues (not timed)
         {
             rays = 0;
+            const int n = pass ? frames : k;
             auto t0 = std::chrono::high_resolution_clock::now();
-            for (int f = 0; f < (pass ? frames : k) && rc == R1_OK; ++f)
+            for (int f = 0; f < n && rc == R1_OK; ++f)
             {
                 const size_t s = (size_t)(f % k);
                 if (f >= k) // the slot's previous frame has to have landed before its buffer is reused
                 {
-                    rc = r1_sync(ctx[s]);
+                    rc = wait(s);
                     rays += *(const uint64_t *)(host[s] + rec - 8);
                 }
                 if (rc == R1_OK)
-                    rc = r1_render_async(ctx[s], &p, host[s], (uint64_t *)(host[s] + rec - 8), nullptr);
+                    rc = enqueue(s);
             }
             for (int i = 0; i < k && rc == R1_OK; ++i)
             {
-                rc = r1_sync(ctx[(size_t)i]);
-                if (i < (pass ? frames : k))
+                rc = wait((size_t)i);
+                if (i < n)
                     rays += *(const uint64_t *)(host[(size_t)i] + rec - 8);
             }
             secs = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
         }
     }
     if (rc == R1_OK)
-        printf("%s pipelined:  %d frames, %d in flight, %.3f ms per frame, %llu rays, %0.2f mrays/s (pixels + count on the host)\n", scene_name, frames,
-               k, secs / frames * 1e3, (unsigned long long)rays, rays / secs / 1e6);
+        printf("%s pipelined:  %d frames, %d in flight%s, %.3f ms per frame, %llu rays, %0.2f mrays/s (pixels + count on the host)\n", scene_name, frames,
+               k, multi ? " (each split over the devices, RCCL all-gather)" : "", secs / frames * 1e3, (unsigned long long)rays, rays / secs / 1e6);
     else
         fprintf(stderr, "pipelined %s: %s\n", scene_name, r1_last_error());
     for (int i = 0; i < k; ++i)
     {
         r1_host_free(host[(size_t)i]);
         r1_destroy(ctx[(size_t)i]);
+        r1_multi_destroy(mul[(size_t)i]);
     }
     r1_host_scene_destroy(hs);
     return rc == R1_OK ? 0 : 1;

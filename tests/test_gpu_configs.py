@@ -440,6 +440,15 @@ def test_rayweek1_hip_pipeline_mode_counts_the_same_rays(tmp_path):
         m = re.search(rf"{name} pipelined:  7 frames, 3 in flight, [\d.]+ ms per frame, (\d+) rays, [\d.]+ mrays/s", text)
         assert m, text
         assert int(m.group(1)) == 7 * single[name]
+    # the same with every frame split over the devices of an r1_multi (one device here: a one-rank RCCL communicator per frame in flight)
+    out = subprocess.run([exe, "--width", "160", "--height", "96", "--spp", "3", "--pipeline", "5", "--inflight", "2", "--devices", "1", "--gather", "rccl"],
+                         cwd=tmp_path, capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()
+    text = out.stdout.decode()
+    for name in ("small", "medium", "large"):
+        m = re.search(rf"{name} pipelined:  5 frames, 2 in flight \(each split over the devices, RCCL all-gather\), [\d.]+ ms per frame, (\d+) rays", text)
+        assert m, text
+        assert int(m.group(1)) == 5 * single[name]
 
 
 # ---- PIXEL mode of the throughput entry point (r1_set_pixel_mode) --------------------------------------
