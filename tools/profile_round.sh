@@ -34,7 +34,8 @@ for k in 2 4 8; do
   timeout -k 10 120 python bench.py --steps 320 --warmup 32 --no-cpu-baseline --no-extras --emulate-shards $k --rccl-selftest 2>/dev/null | tail -1 > $OUT/emulate_shards_$k.json || echo "emulate $k failed"
   timeout -k 10 120 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --emulate-shards $k --rccl-selftest 2>/dev/null | tail -1 > $OUT/emulate_shards_${k}_steps20.json || echo "emulate $k short failed"
 done
-timeout -k 10 120 python bench.py --gpus 1 --multi inproc --steps 50 --warmup 5 --check > $OUT/bench_line_inproc_one_gpu.json 2>/dev/null || echo "inproc failed"
+timeout -k 10 120 python bench.py --gpus 1 --multi inproc --steps 300 --warmup 20 --check > $OUT/bench_line_inproc_one_gpu.json 2>/dev/null || echo "inproc failed"
+timeout -k 10 120 python bench.py --gpus 1 --multi inproc --inflight 1 --steps 50 --warmup 5 --check > $OUT/bench_line_inproc_one_gpu_sync.json 2>/dev/null || echo "inproc sync failed"
 timeout -k 10 120 python tools/bvh_stats.py large 1200 800 10 > $OUT/traversal_stats_tree_kernel.txt 2>&1
 timeout -k 10 120 python tools/kernel_stats.py large 1200 800 10 > $OUT/phase_stats_sweep_kernel.txt 2>&1
 timeout -k 10 120 python tools/wave_timeline.py > $OUT/wave_timeline_sync_frame.txt 2>&1
