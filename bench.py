@@ -223,8 +223,11 @@ def parse_args(argv=None):
                     help="with --emulate-shards K on one GPU: also run the rank path's RCCL all-gather per frame through a ONE-rank "
                          "communicator (the collective's launch cost next to a 1/K frame; the data does not leave the GPU)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
-    ap.add_argument("--check", action="store_true",
-                    help="after the timed region compare the image and ray count that landed on the host with an unsharded render")
+    ap.add_argument("--check", action="store_true", default=True,
+                    help="(default) after the timed region compare the image and ray count that landed on the host with ONE synchronous, "
+                         "unsharded r1_render of the same frame — another build of the kernel (latency mode), so `check: true` in the line "
+                         "says the timed frames' pixels and count are the frame's")
+    ap.add_argument("--no-check", dest="check", action="store_false")
     ap.add_argument("--pixel-mode", action="store_true",
                     help="r1_set_pixel_mode: lanes own pixels, 3 B/pixel written, no per-sample workspace, no resolve launch (~10 %% slower)")
     ap.add_argument("--no-host-copy", action="store_true", help="`value` = frames left in HBM (round 2's headline mode), no copies to the host")
@@ -291,33 +294,44 @@ def run_inproc(args):
     w, h, spp = args.width, args.height, args.spp
     gw, gh = (int(v) for v in args.grid.split("x")) if args.scene == "grid" else (0, 0)
     scene = r1.Scene(SCENE_KIND[args.scene], w, h, gw, gh)
+    # frames per launch: as for ranks, a device's share of one frame is a small launch at N >= 3 (run_ranks)
+    B = args.batch if args.batch > 0 else (1 if n < 3 or lanes == 1 else max(1, min(n, args.steps // 16)))
     multis = [binding.MultiRenderer(list(range(n))) for _ in range(lanes)]
     for m_ in multis:
         m_.set_scene(scene)
-    hosts = [binding.HostFrames(w, h, 1) for _ in range(lanes)]
+    hosts = [binding.HostFrames(w, h, B) for _ in range(lanes)]
+    pending = [0] * lanes
     p = r1.make_params(w, h, spp, args.seed, variant=args.variant)
     img = np.zeros((h, w, 3), np.uint8)
     counter = [0]
     dev_s = [0.0]
 
     def step():
-        k = counter[0] % lanes
+        k = (counter[0] // B) % lanes
         counter[0] += 1
         if lanes == 1:
             rays, s = multis[0].render_into(p, img)
             dev_s[0] += s
             return rays
-        multis[k].render_async(p, hosts[k])
+        pending[k] += 1
+        if pending[k] == B:
+            multis[k].render_batch_async(p, B, hosts[k], 0)
+            pending[k] = 0
         return None
 
     def fence():
+        for k in range(lanes):  # a partial last batch
+            if pending[k]:
+                multis[k].render_batch_async(p, pending[k], hosts[k], 0)
+                pending[k] = 0
+        counter[0] = 0
         for m_ in multis:
             m_.sync()
         for d in range(n):
             torch.cuda.synchronize(d)
 
     for _ in range(2):  # setup: buffers, communicators, hardware queues
-        for _ in range(lanes):
+        for _ in range(lanes * B):
             step()
         fence()
     for _ in range(args.warmup):
@@ -347,12 +361,12 @@ def run_inproc(args):
         rend.close()
     cfg = workload_config(args, info["first_device"], n, rays_per_step)
     cfg.update({"parallelism": f"tile-split x{n}, ONE process (r1_multi: ncclCommInitAll, one ncclAllGather per frame, RCCL {info['rccl_version']})",
-                "value_mode": (f"{lanes} frames in flight = {lanes} r1_multi objects (own communicator + streams each), r1_multi_render_async: every frame "
+                "value_mode": (f"{lanes * B} frames in flight = {lanes} r1_multi objects (own communicator + streams each) x {B} frames per launch, r1_multi_render[_batch]_async: every frame "
                                "ends with its pixels + ray count copied to page-locked HOST memory by device 0 (rayweek1.cpp:848 -> :891, pipelined)")
                               if lanes > 1 else
                               "one synchronous frame at a time through r1_multi_render: dispatch -> pixels + ray count on the host "
                               "(rayweek1.cpp:848 -> :891); latency-mode kernels, no frames in flight",
-                "frames_in_flight": lanes, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                "frames_in_flight": lanes * B, "launches_in_flight": lanes, "frames_per_launch": B, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "workgroups": info["first_device"]["blocks"], "threads_per_workgroup": info["first_device"]["threads_per_block"],
                 "host_submit_ms_per_step": submit / args.steps * 1e3,
                 "device_ms_per_step": dev_s[0] / args.steps * 1e3 if lanes == 1 else None})

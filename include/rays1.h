@@ -324,6 +324,9 @@ int r1_multi_render(r1_multi *m, const r1_params *params, uint8_t *rgb_out, uint
  * it into `host_frame`, page-locked memory).  Nothing is waited for; r1_multi_sync waits for this object's frame.  A caller
  * keeps K frames in flight with K r1_multi objects (each owns a communicator), as K r1_contexts do on one GPU. */
 int r1_multi_render_async(r1_multi *m, const r1_params *params, void *host_frame);
+/* The same for a batch of n_frames frames (seeds params->seed + f * seed_stride) per launch, all-gather and copy (see
+ * r1_render_batch_async): host_frames receives n_frames frame records. */
+int r1_multi_render_batch_async(r1_multi *m, const r1_params *params, int32_t n_frames, uint32_t seed_stride, void *host_frames);
 int r1_multi_sync(r1_multi *m);
 /* Facts for reports: device count, RCCL version code (ncclGetVersion), launch info of the first device. */
 int r1_multi_info(r1_multi *m, int32_t *n_devices, int32_t *rccl_version, r1_launch_info *first_device);

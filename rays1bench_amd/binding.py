@@ -114,6 +114,7 @@ SYMBOLS = [
     ("r1_multi_set_scene", C.c_int, [C.c_void_p, C.POINTER(CScene), C.POINTER(CCamera)]),
     ("r1_multi_render", C.c_int, [C.c_void_p, C.POINTER(Params), _u8p, _u64p, _dblp]),
     ("r1_multi_render_async", C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p]),
+    ("r1_multi_render_batch_async", C.c_int, [C.c_void_p, C.POINTER(Params), C.c_int32, C.c_uint32, C.c_void_p]),
     ("r1_multi_sync", C.c_int, [C.c_void_p]),
     ("r1_multi_info", C.c_int, [C.c_void_p, _i32p, _i32p, C.POINTER(LaunchInfo)]),
     ("r1_assemble_device", C.c_int, [_ctx, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -442,6 +443,9 @@ class MultiRenderer:
     def render_async(self, params, host_frames):
         """r1_multi_render_async: enqueue one frame over the N GPUs; its record lands in `host_frames` (a HostFrames of 1)."""
         _check(lib().r1_multi_render_async(self._m, C.byref(params), C.c_void_p(host_frames.ptr)))
+
+    def render_batch_async(self, params, n_frames, host_frames, seed_stride=0):
+        _check(lib().r1_multi_render_batch_async(self._m, C.byref(params), n_frames, seed_stride, C.c_void_p(host_frames.ptr)))
 
     def sync(self):
         _check(lib().r1_multi_sync(self._m))

@@ -389,16 +389,18 @@ extern "C" int r1_multi_render(r1_multi *m, const r1_params *params, uint8_t *rg
     return R1_OK;
 }
 
-// Frames in flight across N GPUs from ONE process: the enqueue-only form of r1_multi_render.  Every device renders its tiles with
+// Frames in flight across N GPUs from ONE process: the enqueue-only form of r1_multi_render, for one frame or a BATCH of frames
+// (r1_render_shard_device_batch on every device, ONE all-gather of the n_frames records per device, one assemble, one copy: a device's
+// share of a single frame is a small launch at N >= 4).  Every device renders its tiles with
 // the THROUGHPUT kernels (few long-lived waves per frame), the records go through this r1_multi's own all-gather, device 0 assembles
 // image + summed ray count into one frame record and copies it into `host_frame` (r1_frame_record_bytes, page-locked) — all on the
 // object's streams, nothing is waited for.  A caller keeps K frames in flight with K r1_multi objects (each has its own communicator:
 // collectives of different frames never share one), exactly as K r1_contexts do on one GPU; r1_multi_sync waits for this object's frame.
-extern "C" int r1_multi_render_async(r1_multi *m, const r1_params *params, void *host_frame)
+extern "C" int r1_multi_render_batch_async(r1_multi *m, const r1_params *params, int32_t n_frames, uint32_t seed_stride, void *host_frames)
 {
-    if (!m || !params || !host_frame)
+    if (!m || !params || !host_frames || n_frames < 1)
     {
-        r1_set_error("r1_multi_render_async: null argument");
+        r1_set_error("r1_multi_render_batch_async: bad argument");
         return R1_EINVAL;
     }
     r1_params p = *params;
@@ -407,7 +409,7 @@ extern "C" int r1_multi_render_async(r1_multi *m, const r1_params *params, void 
     if (record == 0 || frame == 0)
         return R1_EINVAL;
     {
-        const int rc_buf = multi_buffers(m, record, frame);
+        const int rc_buf = multi_buffers(m, record * (size_t)n_frames, frame * (size_t)n_frames);
         if (rc_buf != R1_OK)
             return rc_buf;
     }
@@ -424,11 +426,11 @@ extern "C" int r1_multi_render_async(r1_multi *m, const r1_params *params, void 
         q.shard = i;
         if (hipSetDevice(m->device[i]) != hipSuccess)
         {
-            r1_set_error("r1_multi_render_async: cannot select device %d", m->device[i]);
+            r1_set_error("r1_multi_render_batch_async: cannot select device %d", m->device[i]);
             rc = R1_EHIP;
             break;
         }
-        rc = r1_render_shard_device(m->ctx[i], &q, m->d_record[i], (char *)m->d_record[i] + record - 8, m->stream[i]);
+        rc = r1_render_shard_device_batch(m->ctx[i], &q, n_frames, seed_stride, m->d_record[i], m->stream[i]);
     }
     if (rc != R1_OK)
         return drain(rc);
@@ -438,22 +440,27 @@ extern "C" int r1_multi_render_async(r1_multi *m, const r1_params *params, void 
         r1_set_error("ncclGroupStart failed: %s", m->rccl.GetErrorString(nr));
         return drain(R1_EHIP);
     }
-    for (int i = 0; i < m->n && nr == 0; ++i)
-        nr = m->rccl.AllGather(m->d_record[i], m->d_gathered[i], record, R1_NCCL_UINT8, m->comm[i], m->stream[i]);
+    for (int i = 0; i < m->n && nr == 0; ++i) // [device][frame][record]
+        nr = m->rccl.AllGather(m->d_record[i], m->d_gathered[i], record * (size_t)n_frames, R1_NCCL_UINT8, m->comm[i], m->stream[i]);
     const ncclResult_t ne = m->rccl.GroupEnd();
     if (nr != 0 || ne != 0)
     {
-        r1_set_error("ncclAllGather of the frame's records failed: %s", m->rccl.GetErrorString(nr != 0 ? nr : ne));
+        r1_set_error("ncclAllGather of the batch's records failed: %s", m->rccl.GetErrorString(nr != 0 ? nr : ne));
         return drain(R1_EHIP);
     }
     hipError_t he = hipSetDevice(m->device[0]);
-    rc = he == hipSuccess ? r1_assemble_device_records(m->ctx[0], &p, m->d_gathered[0], m->d_rgb, (char *)m->d_rgb + frame - 8, m->stream[0]) : R1_EHIP;
-    if (rc == R1_OK && hipMemcpyAsync(host_frame, m->d_rgb, frame, hipMemcpyDeviceToHost, m->stream[0]) != hipSuccess)
+    rc = he == hipSuccess ? r1_assemble_device_records_batch(m->ctx[0], &p, n_frames, m->d_gathered[0], m->d_rgb, m->stream[0]) : R1_EHIP;
+    if (rc == R1_OK && hipMemcpyAsync(host_frames, m->d_rgb, frame * (size_t)n_frames, hipMemcpyDeviceToHost, m->stream[0]) != hipSuccess)
     {
-        r1_set_error("r1_multi_render_async: copy to the host failed");
+        r1_set_error("r1_multi_render_batch_async: copy to the host failed");
         rc = R1_EHIP;
     }
     return rc == R1_OK ? R1_OK : drain(rc);
+}
+
+extern "C" int r1_multi_render_async(r1_multi *m, const r1_params *params, void *host_frame)
+{
+    return r1_multi_render_batch_async(m, params, 1, 0u, host_frame);
 }
 
 extern "C" int r1_multi_sync(r1_multi *m)

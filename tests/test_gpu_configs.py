@@ -356,6 +356,38 @@ def test_r1_multi_one_rank_communicator_equals_the_plain_render(renderer):
     assert e.value.code == binding.R1_EINVAL
 
 
+def test_r1_multi_batches_in_flight_equal_the_plain_renders(renderer):
+    """r1_multi_render_batch_async: three frames (seeds s, s+7, s+14) per launch, ONE all-gather and one copy for the batch, two
+    r1_multi objects in flight; every frame that lands on the host is the plain r1_render of its seed."""
+    w, h, spp = 333, 211, 5
+    sc = r1.create_large_scene(w, h)
+    renderer.set_scene(sc)
+    ms = [binding.MultiRenderer([0]) for _ in range(2)]
+    hosts = [binding.HostFrames(w, h, 3) for _ in range(2)]
+    try:
+        for m in ms:
+            m.set_scene(sc)
+        for k, m in enumerate(ms):
+            m.render_batch_async(r1.make_params(w, h, spp, 100 + k), 3, hosts[k], seed_stride=7)
+        for m in ms:
+            m.sync()
+        for k in range(2):
+            for f in range(3):
+                ref, ref_rays, _ = renderer.render(r1.make_params(w, h, spp, 100 + k + 7 * f))
+                assert hosts[k].rays(f) == ref_rays and hosts[k].image(f).tobytes() == ref.tobytes(), (k, f)
+        ms[0].render_async(r1.make_params(w, h, spp, 5), hosts[0])   # the one-frame form is the batch of one
+        ms[0].sync()
+        ref, ref_rays, _ = renderer.render(r1.make_params(w, h, spp, 5))
+        assert hosts[0].rays(0) == ref_rays and hosts[0].image(0).tobytes() == ref.tobytes()
+        with pytest.raises(r1.R1Error):
+            ms[0].render_batch_async(r1.make_params(w, h, spp, 5), 0, hosts[0])
+    finally:
+        for m in ms:
+            m.close()
+        for hf in hosts:
+            hf.close()
+
+
 def test_rayweek1_hip_gather_rccl_one_device(tmp_path):
     """The drop-in program with --gather rccl (one-rank communicator here): same report block, same files,
     same pixels and ray counts as the plain run."""

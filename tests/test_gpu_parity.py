@@ -552,8 +552,8 @@ def test_bench_in_process_multi_mode_one_gpu():
         pytest.skip("runs the program's own kernel choice: once is enough")
     import subprocess
     import sys
-    for inflight, mode in (("1", "one synchronous frame"), ("4", "4 frames in flight")):
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--multi", "inproc", "--steps", "9", "--warmup", "2",
+    for inflight, batch, mode in (("1", "0", "one synchronous frame"), ("4", "0", "4 frames in flight"), ("3", "2", "6 frames in flight")):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--multi", "inproc", "--steps", "9", "--warmup", "2", "--batch", batch,
                               "--inflight", inflight, "--check", "--width", "300", "--height", "200", "--spp", "4"], capture_output=True, timeout=600, cwd=ROOT)
         assert out.returncode == 0, out.stderr.decode()[-2000:]
         line = json.loads(out.stdout.decode().strip().splitlines()[-1])
