@@ -765,8 +765,9 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     // kernel mode: the host-returning entry points run in latency mode, the throughput entry point with few long-lived
     // waves per frame — per-sample records + r1_resolve_kernel either way, unless r1_set_pixel_mode chose PIXEL mode
     // for the throughput entry point (a lane owns a pixel: no sample records, no resolve launch, ~10 % slower)
-    // big-scene kernels: > 1023 hittable spheres (10-bit hit indices), or — tree kernels — a node table too large for LDS
-    const int big_scene_ = (c->n_active > R1_MAX_ACTIVE_10BIT || ((variant == 4 || variant == 5) && c->n_bvh_nodes > R1_NODES_LDS_MAX)) ? 1 : 0;
+    // big-scene kernels: > 1023 hittable spheres (10-bit hit indices), or — tree kernels — a node table too large for LDS, or a tree whose
+    // pad is measured per node (small spheres: only the kernels that walk the table in global memory carry that arm, bvh_advance)
+    const int big_scene_ = (c->n_active > R1_MAX_ACTIVE_10BIT || ((variant == 4 || variant == 5) && (c->n_bvh_nodes > R1_NODES_LDS_MAX || c->bvh_pad_local))) ? 1 : 0;
     static const int tp_mode_env = (int)r1_knob("R1_TP_MODE", -1); // tuning experiments
     const int tp_mode = c->pixel_mode ? 2 : (tp_mode_env >= 0 && tp_mode_env <= 2 ? tp_mode_env : 0);
     const int mode = variant == 6 ? 0 : r1_trace_mode(variant, big_scene_, throughput_mode ? tp_mode : 1);

@@ -611,7 +611,9 @@ __device__ __forceinline__ bool bvh_box(const float mx, const float my, const fl
     const float tn = fmaxf(fmaxf(ax - bx, ay - by), az - bz);
     const float tf = fminf(fminf(ax + bx, ay + by), az + bz);
     t_near = tn;
-    return tn <= fminf(tf, best) && tf >= 0.0f;
+    // (three compares instead of tn <= fminf(tf, best): fminf makes the compiler canonicalise `best` every trip; a NaN tn or tf
+    //  — every axis unconstrained — fails them either way)
+    return tn <= tf && tn <= best && tf >= 0.0f;
 }
 
 // Up to TWO sphere pairs (four spheres) of a leaf for this lane's ray: first pass 1 of Hitable::hit for all
@@ -639,30 +641,32 @@ __device__ __forceinline__ void leaf_quad(const float4 *__restrict__ prims, cons
         const float c = __fmaf_rn(coz, coz, __fmaf_rn(coy, coy, cox * cox)) - rsq;
         ds[q] = nb[q] * nb[q] - c;
     }
-    uint32_t mask = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-        mask |= (__float_as_uint(ds[q]) >> 31) ? 0u : (1u << q);
-    if (pairs < 2u)
-        mask &= 3u;
+    // bit q of `mask`: slot q's discriminant has a clear sign bit (rayweek1.cpp:204).  The four sign bits are shifted together with
+    // v_alignbit_b32 ((hi:lo) >> 31 = hi << 1 | sign of lo): 4 + 3 instructions instead of 12 for compare + select + or per slot.
+    uint32_t sgn = __float_as_uint(ds[3]) >> 31;
+    sgn = __builtin_amdgcn_alignbit(sgn, __float_as_uint(ds[2]), 31u);
+    sgn = __builtin_amdgcn_alignbit(sgn, __float_as_uint(ds[1]), 31u);
+    sgn = __builtin_amdgcn_alignbit(sgn, __float_as_uint(ds[0]), 31u);
+    uint32_t mask = ~sgn & (pairs < 2u ? 3u : 15u);
+    // Straight-line body, selects instead of branches: every lane of the leaf runs every trip (a lane without a flagged sphere left
+    // computes on slot 3's numbers and is kept from the update by `have`), and the sphere's index is fetched before its offer is
+    // known to count.  The branched form (only lanes with a flagged sphere, the index only for an offer in range) cost seven register
+    // moves per trip for the loop-carried best / best_id and two exec-mask regions.
     while (__ballot(mask != 0u)) // wave-uniform
     {
-        if (mask)
-        {
-            const uint32_t q = (uint32_t)__ffs((int)mask) - 1u;
-            mask &= mask - 1u;
-            const float n_ = q == 0u ? nb[0] : (q == 1u ? nb[1] : (q == 2u ? nb[2] : nb[3]));
-            const float d_ = q == 0u ? ds[0] : (q == 1u ? ds[1] : (q == 2u ? ds[2] : ds[3]));
-            const float root = ieee_sqrt(d_);
-            const float t1 = n_ - root;
-            const float t = (t1 > 0.001f) ? t1 : n_ + root;
-            if (t > 0.001f && t < FLT_MAX && t <= best)
-            {
-                const uint32_t id = ids[2 * (size_t)first + q];
-                if (t < best || id < best_id)
-                    best = t, best_id = id;
-            }
-        }
+        const bool have = mask != 0u;
+        const uint32_t q = (uint32_t)__builtin_ctz(mask | 8u); // the lowest flagged slot; 3 for a lane that has none left
+        mask &= mask - 1u;
+        const float n_ = q == 0u ? nb[0] : (q == 1u ? nb[1] : (q == 2u ? nb[2] : nb[3]));
+        const float d_ = q == 0u ? ds[0] : (q == 1u ? ds[1] : (q == 2u ? ds[2] : ds[3]));
+        const uint32_t id = ids[2 * (size_t)first + q];
+        const float root = ieee_sqrt(d_);
+        const float t1 = n_ - root;
+        const float t = (t1 > 0.001f) ? t1 : n_ + root;
+        // (bitwise on purpose: && / || become nested exec-mask regions)
+        const bool upd = have & (t > 0.001f) & (t < FLT_MAX) & ((t < best) | ((t == best) & (id < best_id)));
+        best = upd ? t : best;
+        best_id = upd ? id : best_id;
     }
 }
 
@@ -737,7 +741,7 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
         if (CARRY && R1_CARRY_DIV * (uint32_t)__popcll(walking) <= n_alive)
             break; // (n_alive <= 3: never true while a lane walks, so the last walks of a wave run to their end)
         // inner nodes: descend to the nearer child, remember the farther one
-        while (!(cur & LEAF_BIT))
+        while (cur < LEAF_BIT) // (R1_BVH_DONE has the leaf bit set in either form: one compare)
         {
             if (STATS)
             {
@@ -758,7 +762,10 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
                 q3 = nodes[4 * (size_t)cur + 3];
             float tn0, tn1;
             float dist2 = r2;
-            if (S.bvh_pad_local) // wave-uniform: scenes of small spheres measure the pad's distance per node, |m0 + m1 - 2 o|^2
+            // wave-uniform: scenes of small spheres measure the pad's distance per node, |m0 + m1 - 2 o|^2.  They run through the kernels
+            // that read the node table from global memory (r1_capi.cpp enqueue_frame), so the LDS-table kernels carry neither the branch
+            // nor the register move that merges the two distances.
+            if (!LN && S.bvh_pad_local)
             {
                 const float sx = __fmaf_rn(-2.0f, o.x, q0.x + q0.y), sy = __fmaf_rn(-2.0f, o.y, q0.z + q0.w), sz = __fmaf_rn(-2.0f, o.z, q1.x + q1.y);
                 dist2 = __fmaf_rn(sz, sz, __fmaf_rn(sy, sy, sx * sx));
