@@ -535,6 +535,28 @@ void r1_build_bvh(uint32_t na, const float *cx, const float *cy, const float *cz
             }
         }
     }
+    // Trees whose pad is measured from the scene's centre: ONE A for the whole tree (the largest of the nodes': pad only grows) and
+    // every node's K folded into its half extents, e' = e + K rounded up — b = e |1/d| + (A R2 + K) |1/d| = e' |1/d| + (A R2) |1/d| —
+    // so that the kernels which keep the table in LDS evaluate A R2 |1/d| once per RAY instead of a fused multiply-add and three
+    // products per node visit (bvh_advance; 51 -> 47 VALU instructions per visit).  The same number of fp32 roundings as before on the
+    // way to b (product, product, fused multiply-add), covered by the same 2^-18 headroom on A and K.  Nodes keep {A, 0} in the pad
+    // slots: the kernels that read the pad per node (table in global memory) and the CPU restatement of the visit rule see the same rule.
+    if (!B.pad_local)
+    {
+        const size_t nn = out.nodes.size() / 16;
+        float a_max = 0.0f;
+        for (size_t n = 0; n < nn; ++n)
+            a_max = std::max(a_max, out.nodes[16 * n + 12]);
+        for (size_t n = 0; n < nn; ++n)
+        {
+            float *q = &out.nodes[16 * n];
+            const double K = q[13];
+            for (int j = 6; j < 12; ++j)
+                if (std::isfinite(q[j])) // (-inf: a child that never passes)
+                    q[j] = round_up((double)q[j] + K);
+            q[12] = a_max, q[13] = 0.0f;
+        }
+    }
     // keep the tables non-empty for the uploader
     if (out.prims.empty())
         out.prims.assign(8, 0.0f), out.ids.assign(2, 0xFFFFFFFFu);

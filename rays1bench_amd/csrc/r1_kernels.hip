@@ -725,6 +725,12 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
     const V3 oi = mk(o.x * inv.x, o.y * inv.y, o.z * inv.z);
     const float rx = o.x - S.bvh_centre[0], ry = o.y - S.bvh_centre[1], rz = o.z - S.bvh_centre[2];
     const float r2 = __fmaf_rn(rz, rz, __fmaf_rn(ry, ry, rx * rx)); // |o - C|^2 of pad = A r2 + K
+    V3 pa_ray = mk(0.0f, 0.0f, 0.0f);
+    if (LN)
+    {
+        const float pad_ray = lnodes[3].x * r2; // the tree's A (every node carries it)
+        pa_ray = mk(pad_ray * ainv.x, pad_ray * ainv.y, pad_ray * ainv.z);
+    }
     float best = tv.best;
     uint32_t best_id = tv.best_id;
     uint32_t cur = tv.cur;
@@ -761,17 +767,21 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
                 q0 = nodes[4 * (size_t)cur + 0], q1 = nodes[4 * (size_t)cur + 1], q2 = nodes[4 * (size_t)cur + 2],
                 q3 = nodes[4 * (size_t)cur + 3];
             float tn0, tn1;
-            float dist2 = r2;
-            // wave-uniform: scenes of small spheres measure the pad's distance per node, |m0 + m1 - 2 o|^2.  They run through the kernels
-            // that read the node table from global memory (r1_capi.cpp enqueue_frame), so the LDS-table kernels carry neither the branch
-            // nor the register move that merges the two distances.
-            if (!LN && S.bvh_pad_local)
+            // The pad.  Table in LDS (LN): A R2 |1/d| of the whole tree, computed once per call (`pa_ray`; the nodes' K are part of
+            // their half extents, r1_bvh.cpp).  Table in global memory: per node, pad = A dist2 + K with dist2 = R2 or — wave-uniform,
+            // scenes of small spheres — |m0 + m1 - 2 o|^2; such trees always run through these kernels (r1_capi.cpp enqueue_frame).
+            V3 pa = pa_ray;
+            if (!LN)
             {
-                const float sx = __fmaf_rn(-2.0f, o.x, q0.x + q0.y), sy = __fmaf_rn(-2.0f, o.y, q0.z + q0.w), sz = __fmaf_rn(-2.0f, o.z, q1.x + q1.y);
-                dist2 = __fmaf_rn(sz, sz, __fmaf_rn(sy, sy, sx * sx));
+                float dist2 = r2;
+                if (S.bvh_pad_local)
+                {
+                    const float sx = __fmaf_rn(-2.0f, o.x, q0.x + q0.y), sy = __fmaf_rn(-2.0f, o.y, q0.z + q0.w), sz = __fmaf_rn(-2.0f, o.z, q1.x + q1.y);
+                    dist2 = __fmaf_rn(sz, sz, __fmaf_rn(sy, sy, sx * sx));
+                }
+                const float pad = __fmaf_rn(q3.x, dist2, q3.y);
+                pa = mk(pad * ainv.x, pad * ainv.y, pad * ainv.z);
             }
-            const float pad = __fmaf_rn(q3.x, dist2, q3.y);
-            const V3 pa = mk(pad * ainv.x, pad * ainv.y, pad * ainv.z);
             const bool h0 = bvh_box(q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, pa, oi, inv, ainv, best, tn0);
             const bool h1 = bvh_box(q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, pa, oi, inv, ainv, best, tn1);
             const uint32_t c0 = __float_as_uint(q3.z), c1 = __float_as_uint(q3.w);
