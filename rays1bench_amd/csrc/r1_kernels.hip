@@ -234,15 +234,18 @@ struct PairBits
     static constexpr int cap = sizeof(IDX) == 2 ? R1_PAIR_CAP_SMALL : R1_PAIR_CAP; // pairs of one wave
 };
 
-__device__ __forceinline__ int wave_inclusive_scan(int v, const int lane)
+// Inclusive prefix sum over the 64 lanes with data-parallel-primitive moves (no LDS round trips: the __shfl_up form was six dependent
+// ds_bpermute_b32 plus compare / select / add each): Kogge-Stone inside every row of 16 lanes (row_shr 1, 2, 4, 8; lanes shifted in from
+// outside the row read 0), then lane 15 of a row added to the next row (row_bcast:15 into rows 1 and 3) and lane 31 to the upper half
+// (row_bcast:31 into rows 2 and 3).  All 64 lanes must be active.
+__device__ __forceinline__ int wave_inclusive_scan(int v, const int /*lane*/)
 {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1)
-    {
-        const int u = __shfl_up(v, off, 64);
-        if (lane >= off)
-            v += u;
-    }
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false); // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false); // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false); // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false); // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false); // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false); // row_bcast:31 -> rows 2, 3
     return v;
 }
 
