@@ -156,11 +156,12 @@ def cpu_baseline_grid(sc, w, h):
 
 
 # flop per unit of the hit tests, counted from r1_kernels.hip (add / mul / compare / min / max = 1, fma = 2):
-#   node visit   pad fma + 3 mul once, then per child box (bvh_box): 3 fma, 3 fma, 3 sub + 2 max, 3 add + 2 min, min + 2 cmp = 25
-#                -> 5 + 2 x 25 = 55 (the round-1 form, which measured |m - o|^2 per box, was 2 x 32)
+#   node visit   per child box (bvh_box): 3 fma, 3 fma, 3 sub + 2 max, 3 add + 2 min, 3 cmp = 25 -> 2 x 25 = 50 for the kernels that keep the
+#                node table in LDS (the pad is evaluated once per ray since round 3); the big-scene kernels evaluate it
+#                per node (fma + 3 mul): 55 (the round-1 form, which measured |m - o|^2 per box, was 2 x 32)
 #   exact_offer  pass 1 of Hitable::hit for one sphere = SURVEY.md §8d's 16 flop (3 sub, mul + 2 fma, mul + 2 fma, sub, mul + sub)
 #   group test   7 fma + 1 sub of the prefilter (sweep_prefilter)                                                       = 15
-FLOP_NODE, FLOP_SPHERE, FLOP_GROUP = 55.0, 16.0, 15.0
+FLOP_NODE, FLOP_NODE_BIG, FLOP_SPHERE, FLOP_GROUP = 50.0, 55.0, 16.0, 15.0
 
 
 def measure_work(rend, p, info, binding):
@@ -177,10 +178,11 @@ def measure_work(rend, p, info, binding):
     if info["kernel"] == 4:
         # 64-bit counters each: [9] node visits, [5] ("cycles_pass1" of the sweep build) sphere-pair tests, [14] leaf trips x lanes
         visits, pairs, leaf_lane_trips = st["candidates"], st["cycles_pass1"], st["leaf_lane_trips"]
+        flop_node = FLOP_NODE_BIG if (info["spheres_active"] > 1023 or info["bvh_nodes"] > 256) else FLOP_NODE  # the big-scene kernels (r1_capi.cpp enqueue_frame)
         return {"source": "R1_VARIANT_BVH_STATS frame (same samples as the timed kernel)", "rays_per_launch": rays,
                 "node_visits_per_ray": visits / rays, "sphere_pair_tests_per_ray": pairs / rays,
-                "flop_per_node_visit": FLOP_NODE, "flop_per_sphere_pair_test": 2 * FLOP_SPHERE,
-                "flop_per_launch": visits * FLOP_NODE + pairs * 2 * FLOP_SPHERE,
+                "flop_per_node_visit": flop_node, "flop_per_sphere_pair_test": 2 * FLOP_SPHERE,
+                "flop_per_launch": visits * flop_node + pairs * 2 * FLOP_SPHERE,
                 "lane_utilisation": {"at_hit_test": st["alive_lanes"] / (64.0 * it),
                                      "node_loop": visits / (64.0 * max(st["candidate_loop_trips"], 1)),
                                      "leaf_loop": leaf_lane_trips / (64.0 * max(st["overflow_lanes"], 1))}}

@@ -23,7 +23,7 @@
 
 extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int big, int mode, int blocks, hipStream_t stream);
 extern "C" int r1_trace_mode(int variant, int big, int wanted); // 0 samples + one queue, 1 latency, 2 pixel: what is built for (variant, big)
-extern "C" hipError_t r1_launch_resolve(const R1ResolveArgs *args, hipStream_t stream);
+extern "C" hipError_t r1_launch_resolve(const R1ResolveArgs *args, int max_rows, hipStream_t stream);
 extern "C" hipError_t r1_launch_wavefront(R1WaveArgs *w, int blocks, hipStream_t stream);
 extern "C" hipError_t r1_launch_assemble(const void *blocks, void *rgb, int width, int height, int tile_w, int tile_h, int tiles_x, int num_shards,
                                          size_t shard_stride, int n_frames, size_t frame_in, size_t frame_out, size_t total_offset, long long total_out,
@@ -1031,8 +1031,9 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
         r.rays_dst = (unsigned long long *)d_rays;
         r.reset = (uint32_t *)c->counters.p;
     }
+    static const int resolve_rows = (int)r1_knob("R1_RESOLVE_ROWS", R1_RESOLVE_ROWS_TP); // tuning experiments
     if (c->n_local_tiles && !pixel_mode)
-        R1_HIP(r1_launch_resolve(&r, st));
+        R1_HIP(r1_launch_resolve(&r, throughput_mode ? resolve_rows : 0, st));
     else if (batch) // a shard without tiles: its frames' counts are zero
         for (int f = 0; f < n_frames; ++f)
             R1_HIP(hipMemsetAsync((char *)d_out + (size_t)f * batch->out_stride + batch->rays_offset, 0, 8, st));

@@ -19,6 +19,7 @@
 #ifndef R1_STACK_LDS_WORDS_TP
 #define R1_STACK_LDS_WORDS_TP 10 // the same for the THROUGHPUT builds of that kernel (MODE 0 / 3), kept apart for experiments: 6 words with the 32-bit
 #endif                           // traversal stack was the first way to seven workgroups (+3 % from the wave, -1.7 % from the deeper global overflow)
+#define R1_RESOLVE_ROWS_TP 256 // frames in flight: rows of workgroups of the resolve launch (0 = one per tile; 16 / 64 / 256 / one per tile: 29.4 / 30.6 / 31.3 / 30.7 Grays/s over 20 steps, 34.9 / 34.85 / 34.87 / 34.7 over 300), see r1_launch_resolve
 #define R1_NODES_LDS_MAX 256  // tree kernel: scenes whose tree has at most this many nodes (16 KB) run the small-scene kernels, which keep
                               // the node table in LDS; bigger trees run the big-scene kernels (node table through the vector L1)
 #define R1_CHUNK 256        // most samples a wave takes from the global queue per atomic (small frames) ...

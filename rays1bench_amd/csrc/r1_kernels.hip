@@ -1884,12 +1884,17 @@ extern "C" hipError_t r1_launch_wavefront(R1WaveArgs *w, int blocks, hipStream_t
     return hipGetLastError();
 }
 
-extern "C" hipError_t r1_launch_resolve(const R1ResolveArgs *args, hipStream_t stream)
+// max_rows: at most this many rows of workgroups (one row walks tiles row, row + rows, ...); 0 = one row per tile.  Frames in flight use
+// FEW, long-lived workgroups: a resolve launch shares the chip with persistent trace workgroups and gets a slot only when one of them
+// exits, so what it costs is the number of slot grants it needs, not its 26 us of work (profiles/r03/burst_timeline_20_frames.txt).
+extern "C" hipError_t r1_launch_resolve(const R1ResolveArgs *args, int max_rows, hipStream_t stream)
 {
     const int tile_pix = args->tile_w * args->tile_h;
     const int bx = (tile_pix + 255) / 256;
     const uint32_t tiles_all = args->n_local_tiles * (args->n_frames ? args->n_frames : 1u);
-    const int by = (int)(tiles_all < 65535u ? tiles_all : 65535u);
+    int by = (int)(tiles_all < 65535u ? tiles_all : 65535u);
+    if (max_rows > 0 && by > max_rows)
+        by = max_rows;
     hipLaunchKernelGGL(r1_resolve_kernel, dim3(bx, by), dim3(256), 0, stream, *args);
     if (args->frame_rays) // frame batches: per-frame ray counts from the launch's partial sums ([tile of the batch][bx])
         hipLaunchKernelGGL(r1_batch_counts_kernel, dim3(args->n_frames), dim3(256), 0, stream, args->frame_rays, args->n_local_tiles * (uint32_t)bx,
