@@ -599,6 +599,11 @@ def run_ranks(args):
             worst = max(worst, time.perf_counter() - t_)
         fence()
         setup_passes += 1
+        if n > 1:
+            # every rank must run the SAME number of passes (each pass issues collectives): the verdict is the slowest rank's
+            t = torch.tensor([worst], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            worst = float(t.item())
         if setup_passes >= 2 and worst < 2e-3:
             break
     for _ in range(args.warmup):
