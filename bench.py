@@ -745,6 +745,8 @@ def run_ranks(args):
             "note": "executed hit-test flop x frames / wall time / fp32 vector peak (157.3 TFLOP/s).  Low by construction: the count "
                     "leaves out shading, RNG, queue and control instructions, idle lanes of divergent traversals "
                     "(work.lane_utilisation) and the 4-cycle issue of VOP3 instructions; what binds is `valu_issue`.",
+            # N > 1: the work is counted on rank 0's tiles and the peak is ONE GPU's — the figures describe rank 0's GPU, not the job
+            "scope": "the one GPU" if n == 1 else f"rank 0's GPU (its tiles: 1/{n} of every frame) against one GPU's peak",
         }
         cfg = workload_config(args, info, n, rays_per_step)
         host_mb = (img_bytes + 8) / 1e6 if not (sharded and n == 1) else record_bytes / 1e6
