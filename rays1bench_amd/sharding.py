@@ -90,6 +90,14 @@ def assemble_records(gathered, width, height, num_shards, tile_w=32, tile_h=32):
     return assemble(blocks, width, height, num_shards, tile_w, tile_h), rays
 
 
+def assemble_records_batch(gathered, n_frames, width, height, num_shards, tile_w=32, tile_h=32):
+    """Host mirror of r1_assemble_device_records_batch: `gathered` is what ONE all-gather of every rank's n_frames records
+    returns, [rank][frame][record]; returns [(image, total rays)] per frame."""
+    rec = record_bytes(width, height, num_shards, tile_w, tile_h)
+    g = np.asarray(gathered, np.uint8).reshape(num_shards, n_frames, rec)
+    return [assemble_records(np.ascontiguousarray(g[:, f, :]).reshape(-1), width, height, num_shards, tile_w, tile_h) for f in range(n_frames)]
+
+
 def total_rays(gathered, num_shards):
     """Sum of the ray counts in the trailers of a gathered buffer (torch uint8 tensor)."""
     import torch

@@ -62,6 +62,38 @@ def _rank_main(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
+def _rank_batch(rank, world, port, out_dir):
+    """Frame batches: every rank contributes n_frames records to ONE all-gather (bench.py's rank path, r1_render_shard_device_batch):
+    the gathered buffer is [rank][frame][record]; frame f is seeded SEED + f * STRIDE."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_frames, stride = 3, 5
+        sc = r1.create_small_scene(W, H)
+        sa = r1o.SceneArrays.from_c(sc.spheres, sc.camera)
+        recs = []
+        for f in range(n_frames):
+            part, part_rays, _ = r1o.render_frame(sa, r1o.make_params(W, H, SPP, SEED + f * stride, shard=rank, num_shards=world), nthreads=2)
+            recs.append(sharding.make_record(sharding.pack_block(part, rank, world), part_rays))
+        records = torch.from_numpy(np.concatenate(recs))
+        assert records.numel() == n_frames * binding.shard_record_bytes(r1.make_params(W, H, SPP, SEED, shard=rank, num_shards=world))
+        gathered = torch.zeros(world * records.numel(), dtype=torch.uint8)
+        sharding.gather_records(dist, records, gathered)  # the batch's one exchange step
+        frames = sharding.assemble_records_batch(gathered.numpy(), n_frames, W, H, world)
+        for f, (img, rays) in enumerate(frames):
+            full, full_rays, _ = r1o.render_frame(sa, r1o.make_params(W, H, SPP, SEED + f * stride), nthreads=2)
+            assert rays == full_rays and img.tobytes() == full.tobytes(), f
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frame_batches_one_gather_per_batch_gloo(tmp_path):
+    mp.spawn(_rank_batch, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_tile_split_gather_assemble_gloo(world, tmp_path):
     mp.spawn(_rank_main, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
