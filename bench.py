@@ -159,9 +159,10 @@ def cpu_baseline_grid(sc, w, h):
 #   node visit   per child box (bvh_box): 3 fma, 3 fma, 3 sub + 2 max, 3 add + 2 min, 3 cmp = 25 -> 2 x 25 = 50 for the kernels that keep the
 #                node table in LDS (the pad is evaluated once per ray since round 3); the big-scene kernels evaluate it
 #                per node (fma + 3 mul): 55 (the round-1 form, which measured |m - o|^2 per box, was 2 x 32)
+#   root step    the root's leaf (counted with the sphere-pair tests) + ONE box test, outside the walk's loops  = 25
 #   exact_offer  pass 1 of Hitable::hit for one sphere = SURVEY.md §8d's 16 flop (3 sub, mul + 2 fma, mul + 2 fma, sub, mul + sub)
 #   group test   7 fma + 1 sub of the prefilter (sweep_prefilter)                                                       = 15
-FLOP_NODE, FLOP_NODE_BIG, FLOP_SPHERE, FLOP_GROUP = 50.0, 55.0, 16.0, 15.0
+FLOP_NODE, FLOP_NODE_BIG, FLOP_BOX, FLOP_SPHERE, FLOP_GROUP = 50.0, 55.0, 25.0, 16.0, 15.0
 
 
 def measure_work(rend, p, info, binding):
@@ -178,11 +179,13 @@ def measure_work(rend, p, info, binding):
     if info["kernel"] == 4:
         # 64-bit counters each: [9] node visits, [5] ("cycles_pass1" of the sweep build) sphere-pair tests, [14] leaf trips x lanes
         visits, pairs, leaf_lane_trips = st["candidates"], st["cycles_pass1"], st["leaf_lane_trips"]
+        roots = st.get("root_steps", 0)  # the root of the reference's scenes is visited outside the walk's loops: ONE box test + its leaf's pairs
         flop_node = FLOP_NODE_BIG if (info["spheres_active"] > 1023 or info["bvh_nodes"] > 256) else FLOP_NODE  # the big-scene kernels (r1_capi.cpp enqueue_frame)
         return {"source": "R1_VARIANT_BVH_STATS frame (same samples as the timed kernel)", "rays_per_launch": rays,
                 "node_visits_per_ray": visits / rays, "sphere_pair_tests_per_ray": pairs / rays,
+                "root_steps_per_ray": roots / rays, "flop_per_root_step": FLOP_BOX,
                 "flop_per_node_visit": flop_node, "flop_per_sphere_pair_test": 2 * FLOP_SPHERE,
-                "flop_per_launch": visits * flop_node + pairs * 2 * FLOP_SPHERE,
+                "flop_per_launch": visits * flop_node + roots * FLOP_BOX + pairs * 2 * FLOP_SPHERE,
                 "lane_utilisation": {"at_hit_test": st["alive_lanes"] / (64.0 * it),
                                      "node_loop": visits / (64.0 * max(st["candidate_loop_trips"], 1)),
                                      "leaf_loop": leaf_lane_trips / (64.0 * max(st["overflow_lanes"], 1))}}

@@ -125,7 +125,8 @@ enum
                                  box tree chooses the spheres given to the reference's per-sphere test; results
                                  are bit-identical to the exhaustive sweeps   */
     R1_VARIANT_BVH_STATS = 5, /* BVH plus traversal counters (diagnostic; r1_last_stats slots [2] node-loop trips,
-                                 [3] leaf-loop trips, [5] sphere-pair tests, [9] node visits, [14] leaf trips x lanes) */
+                                 [3] leaf-loop trips, [5] sphere-pair tests, [9] node visits, [14] leaf trips x lanes, [15] root steps: the root's leaf and
+                                 the box of its other child tested outside the walk's loops) */
     R1_VARIANT_WAVEFRONT = 6  /* the same tracer as separate generate / intersect / shade kernels with the paths
                                  and per-level queues in HBM; a comparison build: same pixels,
                                  slower than the megakernel; frames of <= 2^24 sample slots       */
@@ -279,7 +280,7 @@ int r1_timing_end(r1_context *ctx, double *trace_ms_sum, double *total_ms_sum, i
 /* Diagnostic counters of the last R1_VARIANT_STATS render through the context's own stream:
  * 16 uint64: [0] wave iterations, [1] alive lanes summed over iterations, [2] candidate-loop
  * trips, [3] lanes that overflowed the candidate list, [4..7] cycles in refill / pass 1 /
- * candidate re-test / shade, [8] wave cycles, [9] candidates, [14] (tree) leaf trips summed over lanes. */
+ * candidate re-test / shade, [8] wave cycles, [9] candidates, [14] (tree) leaf trips summed over lanes, [15] (tree) root steps. */
 int r1_last_stats(r1_context *ctx, uint64_t *out16);
 
 /* Per-wave log of the last R1_VARIANT_*_STATS render: 4 uint64 per wave {start, sample queue found

@@ -323,6 +323,7 @@ class Renderer:
         d["shortest_wave_cycles"] = m - int(out[11])
         d["span_cycles"] = int(out[12]) - (m - int(out[13]))
         d["leaf_lane_trips"] = int(out[14])  # tree diagnostic build: leaf trips summed over lanes
+        d["root_steps"] = int(out[15])       # tree diagnostic build: root steps (one box test + the root's leaf, outside the walk's loops)
         return d
 
     def wave_log(self):

@@ -556,6 +556,25 @@ void r1_build_bvh(uint32_t na, const float *cx, const float *cy, const float *cz
                     q[j] = round_up((double)q[j] + K);
             q[12] = a_max, q[13] = 0.0f;
         }
+        // The root of the reference's scenes is [one leaf of outliers: the ground + the three big balls | the lattice] (the peeling above),
+        // and EVERY ray tests that leaf.  The kernels that keep the table in LDS take this step out of the walk's divergent loops: a ray
+        // that starts its walk tests the root's leaf child (<= 2 pairs) and the box of the other child in straight-line code, together with
+        // the other rays of the wave that start in the same iteration, and the walk begins at the other child (bvh_advance).  The code
+        // for it lives in the bit pattern of the root's K slot: 1 / 2 = child 0 / 1 is such a leaf (as a float 1.4e-45 / 2.8e-45: nothing
+        // to the kernels that still add K to the pad), 0 = no such root.
+        if (nn >= 1)
+        {
+            uint32_t c[2];
+            memcpy(c, &out.nodes[14], 8);
+            uint32_t code = 0;
+            for (int k = 0; k < 2; ++k)
+            {
+                const uint32_t pairs = (c[k] >> 28) & 7u;
+                if ((c[k] & Builder::LEAF) && !(c[1 - k] & Builder::LEAF) && pairs >= 1 && pairs <= 2)
+                    code = (uint32_t)k + 1u;
+            }
+            memcpy(&out.nodes[13], &code, 4);
+        }
     }
     // keep the tables non-empty for the uploader
     if (out.prims.empty())

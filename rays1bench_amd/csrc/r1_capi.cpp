@@ -970,7 +970,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
             return rc;
         R1_HIP(hipMemsetAsync(c->wave_log.p, 0, (size_t)c->wave_log_waves * 32, st));
         c->wave_log_ptr = (unsigned long long)c->wave_log.p;
-        R1_HIP(hipMemcpyAsync((char *)c->counters.p + 128 + 15 * 8, &c->wave_log_ptr, 8, hipMemcpyHostToDevice, st));
+        R1_HIP(hipMemcpyAsync((char *)c->counters.p + 128 + 16 * 8, &c->wave_log_ptr, 8, hipMemcpyHostToDevice, st));
     }
     if (!fused_clear)
         R1_HIP(hipMemsetAsync(d_rays, 0, 8, st));

@@ -742,6 +742,33 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
     // bit 15 / bits 12..14 / 12 bits (see trav_put)
     constexpr uint32_t LEAF_BIT = LN ? 0x8000u : 0x80000000u, INDEX_MASK = LN ? 0x0FFFu : 0x0FFFFFFFu;
     constexpr int COUNT_SHIFT = LN ? 12 : 28;
+    if (LN)
+    {
+        // The root step outside the loops (r1_bvh.cpp: the root of the reference's scenes is [a leaf of <= 2 pairs that every ray tests |
+        // the rest]): the lanes that start a walk in this call (cur == 0: no child reference points at the root) test that leaf and then the
+        // box of the other child, all of them together and in straight-line code, and go on at the other child.  Same offers, same pruning
+        // rule as a visit of node 0 followed by the leaf; one node trip and one leaf trip fewer per ray in the divergent loops below.
+        const uint32_t root_code = __float_as_uint(lnodes[3].y); // wave-uniform: 0 none, 1 / 2 = child 0 / 1 is the leaf
+        if (root_code != 0u && cur == 0u)
+        {
+            const uint32_t c0 = __float_as_uint(lnodes[3].z), c1 = __float_as_uint(lnodes[3].w);
+            const uint32_t leaf = root_code == 1u ? c0 : c1, other = root_code == 1u ? c1 : c0;
+            const uint32_t lp = (leaf >> COUNT_SHIFT) & 7u;
+            if (STATS)
+            {
+                wstat[5] += (unsigned long long)lp, wstat[16] += 1ull, wstat[17] += 1ull; // ([17]: root steps = one box test each, stats slot 15)
+                if ((tid & 63) == __ffsll((long long)__ballot(1)) - 1)
+                    wstat[3] += 1;
+            }
+            leaf_quad(prims, ids, leaf & INDEX_MASK, lp, o, d, best, best_id);
+            // (the other child's box is fetched only now: six more live registers across the leaf test spill in the 7-wave builds)
+            const int k = root_code == 1u ? 1 : 0; // its column in the node's rows
+            const float *nf = (const float *)lnodes;
+            float tn;
+            const bool h = bvh_box(nf[0 + k], nf[2 + k], nf[4 + k], nf[6 + k], nf[8 + k], nf[10 + k], pa_ray, oi, inv, ainv, best, tn);
+            cur = h ? other : R1_BVH_DONE;
+        }
+    }
     for (;;)
     {
         const unsigned long long walking = __ballot(cur != R1_BVH_DONE);
@@ -1238,10 +1265,10 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
 {
     constexpr bool LAT = MODE == 1, PIX = MODE == 2, BATCH = MODE == 3; // MODE 3 = MODE 0 whose queue spans the frames of a batch
     typedef typename IdxType<BIG>::type IDX;
-    unsigned long long wstat[17];
+    unsigned long long wstat[18];
     if (STATS)
     {
-        for (int i = 0; i < 17; ++i)
+        for (int i = 0; i < 18; ++i)
             wstat[i] = 0;
         wstat[14] = __builtin_readcyclecounter();
     }
@@ -1251,7 +1278,7 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
     unsigned long long log_start = 0, log_exhausted = 0;
     if (STATS && A.stats)
     {
-        wave_log = (unsigned long long *)A.stats[15];
+        wave_log = (unsigned long long *)A.stats[16]; // (the word behind the sixteen published slots)
         log_start = __builtin_amdgcn_s_memrealtime();
     }
     // words of the attenuation stack in LDS (the rest of a deep path's entries live in the global workspace)
@@ -1525,8 +1552,8 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
         if (VARIANT == 4)
         {
             // per-lane counters of sweep_bvh
-            const int slots[4] = {2, 3, 5, 16};
-            for (int q = 0; q < 4; ++q)
+            const int slots[5] = {2, 3, 5, 16, 17};
+            for (int q = 0; q < 5; ++q)
             {
                 unsigned long long c = wstat[slots[q]];
                 for (int off = 32; off > 0; off >>= 1)
@@ -1548,7 +1575,10 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
             atomicMax(&A.stats[12], (unsigned long long)__builtin_readcyclecounter());  // last wave end (this XCD's counter)
             atomicMax(&A.stats[13], ~wstat[14]);                    // ~first wave start
             if (VARIANT == 4)
+            {
                 atomicAdd(&A.stats[14], wstat[16]);                 // tree: leaf trips summed over lanes
+                atomicAdd(&A.stats[15], wstat[17]);                 // tree: root steps (bvh_advance) summed over lanes
+            }
         }
     }
 

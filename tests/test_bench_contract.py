@@ -68,8 +68,10 @@ def test_roofline_describes_the_timed_kernel_and_no_frac_exceeds_one():
     w = r["work"]
     assert w["rays_per_launch"] == d["config"]["rays_per_step"]
     if "box tree" in d["config"]["kernel"]:
-        flop = w["rays_per_launch"] * (w["node_visits_per_ray"] * w["flop_per_node_visit"] + w["sphere_pair_tests_per_ray"] * w["flop_per_sphere_pair_test"])
-        assert w["flop_per_node_visit"] == 50 and w["flop_per_sphere_pair_test"] == 32
+        flop = w["rays_per_launch"] * (w["node_visits_per_ray"] * w["flop_per_node_visit"] + w["root_steps_per_ray"] * w["flop_per_root_step"]
+                                       + w["sphere_pair_tests_per_ray"] * w["flop_per_sphere_pair_test"])
+        assert w["flop_per_node_visit"] == 50 and w["flop_per_sphere_pair_test"] == 32 and w["flop_per_root_step"] == 25
+        assert 0 <= w["root_steps_per_ray"] <= 1
         assert 0 < w["lane_utilisation"]["node_loop"] <= 1 and 0 < w["lane_utilisation"]["leaf_loop"] <= 1
     else:
         flop = w["rays_per_launch"] * w["group_tests_per_ray"] * w["flop_per_group_test"] + w["rays_per_launch"] * w["exact_slots_per_ray"] * w["flop_per_exact_slot"]

@@ -32,6 +32,7 @@ it = st["wave_iterations"]
 out = {
     "rays": rays, "waves": waves, "wave_iterations": it,
     "lane_utilisation_at_sweep": st["alive_lanes"] / (64.0 * it),
+    "root_steps_per_ray": st.get("root_steps", 0) / rays,  # the root's leaf + the box of its other child, outside the loops (counted as a leaf trip, not as a node visit)
     "node_visits_per_ray": st["candidates"] / rays,
     "sphere_tests_per_ray": st["cycles_pass1"] / rays,
     "node_loop_trips_per_iteration": st["candidate_loop_trips"] / it,
