@@ -348,6 +348,8 @@ typedef struct r1_bvh_info
     int32_t nodes, leaves, depth, stack_entries, spheres, pairs;
     float centre[3];   /* C of the kernel's box inflation pad = A |o - C|^2 + K (r1_bvh.cpp) */
     int32_t pad_local; /* 1: the tree uses pad = A |m0 + m1 - 2 o|^2 + K instead (scenes of small spheres) */
+    int32_t root_leaf; /* 1 / 2: child 0 / 1 of the root is a leaf of <= 2 sphere pairs and the other child an inner node — the kernels test
+                          that leaf and the other child's box once per ray outside the walk's loops; 0: the root has no such shape */
 } r1_bvh_info;
 int r1_bvh_describe(const r1_scene *scene, int32_t leaf_max, r1_bvh_info *info, float *nodes_out, size_t nodes_cap, uint32_t *ids_out,
                     size_t ids_cap);

@@ -55,7 +55,7 @@ class LaunchInfo(C.Structure):
 
 class BvhInfo(C.Structure):
     _fields_ = [("nodes", C.c_int32), ("leaves", C.c_int32), ("depth", C.c_int32), ("stack_entries", C.c_int32), ("spheres", C.c_int32),
-                ("pairs", C.c_int32), ("centre", C.c_float * 3), ("pad_local", C.c_int32)]
+                ("pairs", C.c_int32), ("centre", C.c_float * 3), ("pad_local", C.c_int32), ("root_leaf", C.c_int32)]
 
 
 def make_params(width, height, spp, seed=10001, max_bounces=50, tile_w=32, tile_h=32, shard=0, num_shards=1, variant=0):

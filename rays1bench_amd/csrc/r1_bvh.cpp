@@ -65,6 +65,7 @@ struct R1Bvh
     uint32_t n_leaves = 0;
     float centre[3] = {0, 0, 0}; // C of the pad formula (see above)
     int pad_local = 0;           // 1: pad measured per node (scenes of small spheres), 0: from `centre`
+    int root_leaf = 0;           // 1 / 2: child 0 / 1 of the root is a leaf of <= 2 sphere pairs and the other child an inner node (the root step), 0: no
 };
 
 namespace
@@ -556,24 +557,22 @@ void r1_build_bvh(uint32_t na, const float *cx, const float *cy, const float *cz
                     q[j] = round_up((double)q[j] + K);
             q[12] = a_max, q[13] = 0.0f;
         }
-        // The root of the reference's scenes is [one leaf of outliers: the ground + the three big balls | the lattice] (the peeling above),
-        // and EVERY ray tests that leaf.  The kernels that keep the table in LDS take this step out of the walk's divergent loops: a ray
-        // that starts its walk tests the root's leaf child (<= 2 pairs) and the box of the other child in straight-line code, together with
-        // the other rays of the wave that start in the same iteration, and the walk begins at the other child (bvh_advance).  The code
-        // for it lives in the bit pattern of the root's K slot: 1 / 2 = child 0 / 1 is such a leaf (as a float 1.4e-45 / 2.8e-45: nothing
-        // to the kernels that still add K to the pad), 0 = no such root.
-        if (nn >= 1)
+    }
+    // The root of the reference's scenes is [one leaf of outliers: the ground + the three big balls | the lattice] (the peeling above),
+    // and EVERY ray tests that leaf.  The tree kernels take this step out of the walk's divergent loops: a ray that starts its walk tests
+    // the root's leaf child (<= 2 pairs) and then the box of the other child in straight-line code, together with the other rays of the
+    // wave that start in the same iteration, and the walk begins at the other child (bvh_advance).  root_leaf says whether the root has
+    // that shape and which child is the leaf.
+    out.root_leaf = 0;
+    if (out.nodes.size() >= 16)
+    {
+        uint32_t c[2];
+        memcpy(c, &out.nodes[14], 8);
+        for (int k = 0; k < 2; ++k)
         {
-            uint32_t c[2];
-            memcpy(c, &out.nodes[14], 8);
-            uint32_t code = 0;
-            for (int k = 0; k < 2; ++k)
-            {
-                const uint32_t pairs = (c[k] >> 28) & 7u;
-                if ((c[k] & Builder::LEAF) && !(c[1 - k] & Builder::LEAF) && pairs >= 1 && pairs <= 2)
-                    code = (uint32_t)k + 1u;
-            }
-            memcpy(&out.nodes[13], &code, 4);
+            const uint32_t pairs = (c[k] >> 28) & 7u;
+            if ((c[k] & Builder::LEAF) && !(c[1 - k] & Builder::LEAF) && pairs >= 1 && pairs <= 2)
+                out.root_leaf = k + 1;
         }
     }
     // keep the tables non-empty for the uploader
@@ -649,6 +648,7 @@ extern "C" int r1_bvh_describe(const r1_scene *s, int32_t leaf_max, r1_bvh_info 
     for (int k = 0; k < 3; ++k)
         info->centre[k] = b.centre[k];
     info->pad_local = b.pad_local;
+    info->root_leaf = b.root_leaf;
     if (nodes_out)
     {
         if (nodes_cap < b.nodes.size())

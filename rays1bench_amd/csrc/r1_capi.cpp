@@ -42,6 +42,7 @@ struct R1Bvh
     uint32_t n_leaves = 0;
     float centre[3] = {0, 0, 0};
     int pad_local = 0;
+    int root_leaf = 0;
 };
 void r1_build_bvh(uint32_t na, const float *cx, const float *cy, const float *cz, const float *rsq, const double *rbound, int leaf_max,
                   R1Bvh &out);
@@ -106,6 +107,7 @@ struct r1_context
     int bvh_depth = 0;
     float bvh_centre[3] = {0, 0, 0};
     int bvh_pad_local = 0;
+    int bvh_root_leaf = 0;
     uint32_t n_active = 0, n_sweep = 0, n_padded_scene = 0, n_groups = 0, n_multi = 0;
     std::vector<uint32_t> active_to_scene;
     R1DeviceCamera cam;
@@ -641,6 +643,7 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
     for (int k = 0; k < 3; ++k)
         c->bvh_centre[k] = bvh.centre[k];
     c->bvh_pad_local = bvh.pad_local;
+    c->bvh_root_leaf = bvh.root_leaf;
     for (int &o : c->occupancy)
         o = 0; // the tree kernels' LDS footprint follows the tree (depth of the traversal stack, size of the node table)
     c->n_groups = ng;
@@ -803,6 +806,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     for (int k = 0; k < 3; ++k)
         a.scene.bvh_centre[k] = c->bvh_centre[k];
     a.scene.bvh_pad_local = (uint32_t)c->bvh_pad_local;
+    a.scene.bvh_root_leaf = (uint32_t)c->bvh_root_leaf;
     a.cam = c->cam;
     a.width = p->width, a.height = p->height, a.spp = p->spp, a.max_bounces = p->max_bounces;
     a.seed = p->seed;

@@ -114,6 +114,7 @@ struct R1DeviceScene
     const uint32_t *bvh_ids;
     float bvh_centre[3];
     uint32_t bvh_pad_local; // 1: pad = A |m0 + m1 - 2 o|^2 + K (scenes of small spheres, r1_bvh.cpp)
+    uint32_t bvh_root_leaf; // 1 / 2: child 0 / 1 of the root is a leaf of <= 2 pairs that every ray tests: the root step of bvh_advance; 0: none
 };
 
 struct R1DeviceCamera

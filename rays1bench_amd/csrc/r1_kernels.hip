@@ -742,32 +742,42 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
     // bit 15 / bits 12..14 / 12 bits (see trav_put)
     constexpr uint32_t LEAF_BIT = LN ? 0x8000u : 0x80000000u, INDEX_MASK = LN ? 0x0FFFu : 0x0FFFFFFFu;
     constexpr int COUNT_SHIFT = LN ? 12 : 28;
-    if (LN)
+    // The root step outside the loops (r1_bvh.cpp: the root of the reference's scenes is [a leaf of <= 2 pairs that every ray tests | the
+    // rest], S.bvh_root_leaf): the lanes that start a walk in this call (cur == 0: no child reference points at the root) test that leaf
+    // and then the box of the other child, all of them together and in straight-line code, and go on at the other child.  Same offers, same
+    // pruning rule as a visit of node 0 followed by the leaf; one node trip and one leaf trip fewer per ray in the divergent loops below.
+    // (the small-scene kernels find the code in the K slot of their LDS copy of node 0 — the trace kernel puts it there, K itself is folded
+    //  into the half extents for their trees — instead of holding a scalar register for it through the whole kernel)
+    const uint32_t root_leaf = LN ? __float_as_uint(lnodes[3].y) : S.bvh_root_leaf;
+    if (root_leaf != 0u && cur == 0u) // (the first condition is wave-uniform)
     {
-        // The root step outside the loops (r1_bvh.cpp: the root of the reference's scenes is [a leaf of <= 2 pairs that every ray tests |
-        // the rest]): the lanes that start a walk in this call (cur == 0: no child reference points at the root) test that leaf and then the
-        // box of the other child, all of them together and in straight-line code, and go on at the other child.  Same offers, same pruning
-        // rule as a visit of node 0 followed by the leaf; one node trip and one leaf trip fewer per ray in the divergent loops below.
-        const uint32_t root_code = __float_as_uint(lnodes[3].y); // wave-uniform: 0 none, 1 / 2 = child 0 / 1 is the leaf
-        if (root_code != 0u && cur == 0u)
+        const int k = root_leaf == 1u ? 1 : 0; // column of the OTHER child in the node's rows
+        const float *nf = (LN || top > 0u) ? (const float *)lnodes : (const float *)nodes; // node 0 (big scenes: in LDS with the top of the tree)
+        const uint32_t leaf = __float_as_uint(nf[14 + (1 - k)]), other = __float_as_uint(nf[14 + k]);
+        const uint32_t lp = (leaf >> COUNT_SHIFT) & 7u;
+        if (STATS)
         {
-            const uint32_t c0 = __float_as_uint(lnodes[3].z), c1 = __float_as_uint(lnodes[3].w);
-            const uint32_t leaf = root_code == 1u ? c0 : c1, other = root_code == 1u ? c1 : c0;
-            const uint32_t lp = (leaf >> COUNT_SHIFT) & 7u;
-            if (STATS)
-            {
-                wstat[5] += (unsigned long long)lp, wstat[16] += 1ull, wstat[17] += 1ull; // ([17]: root steps = one box test each, stats slot 15)
-                if ((tid & 63) == __ffsll((long long)__ballot(1)) - 1)
-                    wstat[3] += 1;
-            }
-            leaf_quad(prims, ids, leaf & INDEX_MASK, lp, o, d, best, best_id);
-            // (the other child's box is fetched only now: six more live registers across the leaf test spill in the 7-wave builds)
-            const int k = root_code == 1u ? 1 : 0; // its column in the node's rows
-            const float *nf = (const float *)lnodes;
-            float tn;
-            const bool h = bvh_box(nf[0 + k], nf[2 + k], nf[4 + k], nf[6 + k], nf[8 + k], nf[10 + k], pa_ray, oi, inv, ainv, best, tn);
-            cur = h ? other : R1_BVH_DONE;
+            wstat[5] += (unsigned long long)lp, wstat[16] += 1ull, wstat[17] += 1ull; // ([17]: root steps = one box test each, stats slot 15)
+            if ((tid & 63) == __ffsll((long long)__ballot(1)) - 1)
+                wstat[3] += 1;
         }
+        leaf_quad(prims, ids, leaf & INDEX_MASK, lp, o, d, best, best_id);
+        // (the other child's box is fetched only now: six more live registers across the leaf test spill in the 7-wave builds)
+        V3 pa = pa_ray;
+        if (!LN)
+        {
+            float dist2 = r2;
+            if (S.bvh_pad_local)
+            {
+                const float sx = __fmaf_rn(-2.0f, o.x, nf[0] + nf[1]), sy = __fmaf_rn(-2.0f, o.y, nf[2] + nf[3]), sz = __fmaf_rn(-2.0f, o.z, nf[4] + nf[5]);
+                dist2 = __fmaf_rn(sz, sz, __fmaf_rn(sy, sy, sx * sx));
+            }
+            const float pad = __fmaf_rn(nf[12], dist2, nf[13]);
+            pa = mk(pad * ainv.x, pad * ainv.y, pad * ainv.z);
+        }
+        float tn;
+        const bool h = bvh_box(nf[0 + k], nf[2 + k], nf[4 + k], nf[6 + k], nf[8 + k], nf[10 + k], pa, oi, inv, ainv, best, tn);
+        cur = h ? other : R1_BVH_DONE;
     }
     for (;;)
     {
@@ -1315,6 +1325,10 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
                 q.z = __uint_as_float(r1_ref16(__float_as_uint(q.z))), q.w = __uint_as_float(r1_ref16(__float_as_uint(q.w)));
             dst[i] = q;
         }
+        // node 0's K slot (0 for these trees: K is part of the half extents) carries the root step's code, see bvh_advance (written by
+        // the thread that copied that row: program order; outside the loop, where the test made the compiler peel and unroll the copy)
+        if (LN && tid == 3)
+            ((float *)dst)[13] = __uint_as_float(A.scene.bvh_root_leaf);
         __syncthreads();
     }
 

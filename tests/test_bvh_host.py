@@ -86,8 +86,7 @@ def test_tree_structure(kind, gw, gh):
             i = ids[s]
             assert (c[i] - r[i] >= m - e - 1e-12).all() and (c[i] + r[i] <= m + e + 1e-12).all()
         # trees padded from the scene's centre carry ONE A and have every K folded into the half extents (r1_bvh.cpp)
-        # (the root's K slot may carry the code of the root step in its bit pattern: 1.4e-45 / 2.8e-45 as a float)
-        assert w2 > 0 and (k > 0 if info["pad_local"] else 0 <= k < 1e-40)
+        assert w2 > 0 and (k > 0 if info["pad_local"] else k == 0)
     assert n_leaf == info["leaves"]
     # the pad formula follows the sphere size: measured from one point of the scene for the reference's scenes, per node
     # for the lattices of small spheres (r1_bvh.cpp)
@@ -358,9 +357,9 @@ def test_outlier_peeling_keeps_the_lattice_boxes_flat_and_the_depth_bounded():
     # the distance to the ground sphere's centre: ~17), so the flatness is read off the lattice child's own two children
     lattice = nodes[int(root[14 + lattice_child])]
     assert lattice[E[0][1]] < 0.6 and lattice[E[1][1]] < 0.6
-    assert (nodes[1:, 13] == 0).all() and (nodes[:, 12] == nodes[0][12]).all() and nodes[0][12] > 0  # one A for the tree, K folded into e
-    # the root step's code in the bit pattern of the root's K slot: child `1 - lattice_child` is the leaf every ray tests
-    assert int(nodes[0].view(np.uint32)[13]) == (1 - lattice_child) + 1
+    assert (nodes[:, 13] == 0).all() and (nodes[:, 12] == nodes[0][12]).all() and nodes[0][12] > 0  # one A for the tree, K folded into e
+    # the root step of the kernels (bvh_advance): child `1 - lattice_child` is the leaf every ray tests
+    assert info["root_leaf"] == (1 - lattice_child) + 1
     # adversarial: radii 4^i (every sphere an outlier of the rest) + a crowd of small ones
     rng = np.random.default_rng(9)
     n_small = 600
