@@ -742,6 +742,60 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
     // bit 15 / bits 12..14 / 12 bits (see trav_put)
     constexpr uint32_t LEAF_BIT = LN ? 0x8000u : 0x80000000u, INDEX_MASK = LN ? 0x0FFFu : 0x0FFFFFFFu;
     constexpr int COUNT_SHIFT = LN ? 12 : 28;
+    // one visit of the inner node `cur`: both children's boxes, nearer child next, farther one on the stack (or the stack's top if neither is hit)
+    auto visit_node = [&]() {
+        if (STATS)
+        {
+            wstat[9] += 1;
+            if ((tid & 63) == __ffsll((long long)__ballot(1)) - 1)
+                wstat[2] += 1;
+        }
+        // {m0x m1x m0y m1y} {m0z m1z e0x e1x} {e0y e1y e0z e1z} {A K child0 child1}
+        float4 q0, q1, q2, q3;
+        if (LN || cur < top)
+        {
+            q0 = lnodes[4 * cur + 0], q1 = lnodes[4 * cur + 1], q2 = lnodes[4 * cur + 2], q3 = lnodes[4 * cur + 3];
+            if (!LN)
+                asm volatile("" : "+v"(q0.x), "+v"(q1.x), "+v"(q2.x), "+v"(q3.x));
+        }
+        else
+            q0 = nodes[4 * (size_t)cur + 0], q1 = nodes[4 * (size_t)cur + 1], q2 = nodes[4 * (size_t)cur + 2],
+            q3 = nodes[4 * (size_t)cur + 3];
+        float tn0, tn1;
+        // The pad.  Table in LDS (LN): A R2 |1/d| of the whole tree, computed once per call (`pa_ray`; the nodes' K are part of
+        // their half extents, r1_bvh.cpp).  Table in global memory: per node, pad = A dist2 + K with dist2 = R2 or — wave-uniform,
+        // scenes of small spheres — |m0 + m1 - 2 o|^2; such trees always run through these kernels (r1_capi.cpp enqueue_frame).
+        V3 pa = pa_ray;
+        if (!LN)
+        {
+            float dist2 = r2;
+            if (S.bvh_pad_local)
+            {
+                const float sx = __fmaf_rn(-2.0f, o.x, q0.x + q0.y), sy = __fmaf_rn(-2.0f, o.y, q0.z + q0.w), sz = __fmaf_rn(-2.0f, o.z, q1.x + q1.y);
+                dist2 = __fmaf_rn(sz, sz, __fmaf_rn(sy, sy, sx * sx));
+            }
+            const float pad = __fmaf_rn(q3.x, dist2, q3.y);
+            pa = mk(pad * ainv.x, pad * ainv.y, pad * ainv.z);
+        }
+        const bool h0 = bvh_box(q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, pa, oi, inv, ainv, best, tn0);
+        const bool h1 = bvh_box(q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, pa, oi, inv, ainv, best, tn1);
+        const uint32_t c0 = __float_as_uint(q3.z), c1 = __float_as_uint(q3.w);
+        if (h0 && h1)
+        {
+            const bool swap = tn1 < tn0;
+            trav_put(trav, sp * R1_BLOCK + tid, swap ? c0 : c1);
+            ++sp;
+            cur = swap ? c1 : c0;
+        }
+        else if (h0)
+            cur = c0;
+        else if (h1)
+            cur = c1;
+        else if (sp > 0)
+            cur = trav_get(trav, --sp * R1_BLOCK + tid);
+        else
+            cur = R1_BVH_DONE;
+    };
     // The root step outside the loops (r1_bvh.cpp: the root of the reference's scenes is [a leaf of <= 2 pairs that every ray tests | the
     // rest], S.bvh_root_leaf): the lanes that start a walk in this call (cur == 0: no child reference points at the root) test that leaf
     // and then the box of the other child, all of them together and in straight-line code, and go on at the other child.  Same offers, same
@@ -778,6 +832,8 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
         float tn;
         const bool h = bvh_box(nf[0 + k], nf[2 + k], nf[4 + k], nf[6 + k], nf[8 + k], nf[10 + k], pa, oi, inv, ainv, best, tn);
         cur = h ? other : R1_BVH_DONE;
+        // (the sibling's own visit taken into this step as well — `if (cur < LEAF_BIT) visit_node();` here — measured 35.5 against 36.2
+        //  Grays/s: a generic visit runs at 0.54 lane utilisation inside the loop and at the ~0.34 of the starting lanes out here)
     }
     for (;;)
     {
@@ -788,59 +844,7 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
             break; // (n_alive <= 3: never true while a lane walks, so the last walks of a wave run to their end)
         // inner nodes: descend to the nearer child, remember the farther one
         while (cur < LEAF_BIT) // (R1_BVH_DONE has the leaf bit set in either form: one compare)
-        {
-            if (STATS)
-            {
-                wstat[9] += 1;
-                if ((tid & 63) == __ffsll((long long)__ballot(1)) - 1)
-                    wstat[2] += 1;
-            }
-            // {m0x m1x m0y m1y} {m0z m1z e0x e1x} {e0y e1y e0z e1z} {A K child0 child1}
-            float4 q0, q1, q2, q3;
-            if (LN || cur < top)
-            {
-                q0 = lnodes[4 * cur + 0], q1 = lnodes[4 * cur + 1], q2 = lnodes[4 * cur + 2], q3 = lnodes[4 * cur + 3];
-                if (!LN)
-                    asm volatile("" : "+v"(q0.x), "+v"(q1.x), "+v"(q2.x), "+v"(q3.x));
-            }
-            else
-                q0 = nodes[4 * (size_t)cur + 0], q1 = nodes[4 * (size_t)cur + 1], q2 = nodes[4 * (size_t)cur + 2],
-                q3 = nodes[4 * (size_t)cur + 3];
-            float tn0, tn1;
-            // The pad.  Table in LDS (LN): A R2 |1/d| of the whole tree, computed once per call (`pa_ray`; the nodes' K are part of
-            // their half extents, r1_bvh.cpp).  Table in global memory: per node, pad = A dist2 + K with dist2 = R2 or — wave-uniform,
-            // scenes of small spheres — |m0 + m1 - 2 o|^2; such trees always run through these kernels (r1_capi.cpp enqueue_frame).
-            V3 pa = pa_ray;
-            if (!LN)
-            {
-                float dist2 = r2;
-                if (S.bvh_pad_local)
-                {
-                    const float sx = __fmaf_rn(-2.0f, o.x, q0.x + q0.y), sy = __fmaf_rn(-2.0f, o.y, q0.z + q0.w), sz = __fmaf_rn(-2.0f, o.z, q1.x + q1.y);
-                    dist2 = __fmaf_rn(sz, sz, __fmaf_rn(sy, sy, sx * sx));
-                }
-                const float pad = __fmaf_rn(q3.x, dist2, q3.y);
-                pa = mk(pad * ainv.x, pad * ainv.y, pad * ainv.z);
-            }
-            const bool h0 = bvh_box(q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, pa, oi, inv, ainv, best, tn0);
-            const bool h1 = bvh_box(q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, pa, oi, inv, ainv, best, tn1);
-            const uint32_t c0 = __float_as_uint(q3.z), c1 = __float_as_uint(q3.w);
-            if (h0 && h1)
-            {
-                const bool swap = tn1 < tn0;
-                trav_put(trav, sp * R1_BLOCK + tid, swap ? c0 : c1);
-                ++sp;
-                cur = swap ? c1 : c0;
-            }
-            else if (h0)
-                cur = c0;
-            else if (h1)
-                cur = c1;
-            else if (sp > 0)
-                cur = trav_get(trav, --sp * R1_BLOCK + tid);
-            else
-                cur = R1_BVH_DONE;
-        }
+            visit_node();
         if (cur != R1_BVH_DONE)
         {
             // leaf: `cnt` PAIRS of spheres {cx_a cx_b cy_a cy_b} {cz_a cz_b rsq_a rsq_b}; an odd
