@@ -125,6 +125,32 @@ def test_bvh_sphere_count_edges(renderer, n_active):
     assert got[1] == orays and got[2].tobytes() == osamples.tobytes()
 
 
+@pytest.mark.parametrize("pick,code", [("first9", 2), ("large", 1), ("first12", 0)])
+def test_root_step_shapes(renderer, pick, code):
+    """bvh_advance's root step (the root's leaf child and the box of its sibling tested outside the walk's loops) for each shape of root
+    r1_bvh_info.root_leaf reports: the leaf is child 1 (nine spheres: [inner | leaf]), child 0 (the large scene's outlier leaf), and no
+    such root (both children inner nodes): the tree kernel equals the reference-form sweep and the oracle either way."""
+    w, h, spp = 96, 64, 3
+    if pick == "large":
+        src = r1.create_large_scene(w, h)
+        sa = r1o.SceneArrays.from_c(src.spheres, src.camera)
+    else:
+        src = r1.create_grid_scene(w, h, 36, 30)
+        arr = src.arrays()
+        keep = np.nonzero(arr["inv_radius"] != 0)[0][:9 if pick == "first9" else 12]
+        sa = r1o.SceneArrays(pad8({k: v[keep] for k, v in arr.items()}), src.camera_array())
+    cs = _as_cscene(sa)
+    info, _, _ = binding.bvh_describe(cs)
+    assert info["root_leaf"] == code, info
+    renderer.set_scene_raw(cs, _as_ccamera(sa))
+    got = renderer.render_samples(r1.make_params(w, h, spp, 21, variant=BVH))
+    assert renderer.launch_info()["kernel"] == BVH
+    ref = renderer.render_samples(r1.make_params(w, h, spp, 21, variant=binding.VARIANT_REFERENCE))
+    assert same(got, ref)
+    oimg, orays, osamples = r1o.render_frame(sa, oparams(r1.make_params(w, h, spp, 21)), want_samples=True)
+    assert got[1] == orays and got[2].tobytes() == osamples.tobytes()
+
+
 CASES = ["mixed_radii", "far_camera", "dense_cluster", "tiny_spheres", "nested", "noise_dominated", "coincident", "collinear"]
 
 
