@@ -131,7 +131,8 @@ struct r1_context
     // one page-locked, device-visible word: the synchronous entry points let the frame's last launch store the ray count
     // straight into host memory (8 bytes over PCIe at the end of r1_resolve_kernel) instead of enqueueing a second copy
     unsigned long long *host_word = nullptr, *host_word_dev = nullptr;
-    int default_variant = 4; // what R1_VARIANT_DEFAULT resolves to for the scene in the context (r1_set_scene)
+    int default_variant = 4;    // what R1_VARIANT_DEFAULT resolves to for the scene in the context (r1_set_scene): synchronous frames
+    int default_variant_tp = 4; // ... and frames in flight (the throughput kernels: measured apart, the two kernel families do not rank alike)
     int occupancy[48] = {0}; // [variant + 8 * big + 16 * mode]
     bool pixel_mode = false; // r1_set_pixel_mode
     DevBuf gstack; // blocks per CU of the trace kernel, by variant
@@ -406,13 +407,15 @@ static std::vector<R1Group> build_groups(uint32_t na, const std::vector<double> 
 }
 
 // ---- R1_VARIANT_DEFAULT for scenes of a few dozen spheres: measured, not guessed ---------------------------------
-// Between R1_TREE_SKIP_MIN and R1_TREE_SKIP_MAX hittable spheres neither kernel wins everywhere: the reference's
-// medium scene (46 spheres packed into a 9 x 2.3 x 8 box) is 4-5 % faster through the ungrouped exhaustive sweep,
+// Between R1_TREE_SKIP_MIN and R1_TREE_SKIP_MAX hittable spheres neither kernel won everywhere in round 2: the reference's
+// medium scene (46 spheres packed into a 9 x 2.3 x 8 box) was 4-5 % faster through the ungrouped exhaustive sweep (since the
+// tree's root step of round 3 the two are within 3 % for a synchronous frame and the tree is 7 % ahead in flight),
 // slices of the large scene's lattice of the same size are 10-35 % faster through the tree
-// (profiles/r02/tree_vs_sweep_crossover.txt), and no cost estimate the builder can make tells the two kinds apart.
+// (profiles/r03/tree_vs_sweep_crossover.txt), and no cost estimate the builder can make tells the two kinds apart.
 // So a scene in that band is timed once per process: a probe frame (R1_PROBE_W x R1_PROBE_H x R1_PROBE_SPP with
-// the scene's own camera, one warm-up + two timed synchronous frames per kernel, the faster counts) decides, and
-// the verdict is remembered under a hash of the scene's arrays and camera, so the other contexts of the process — the
+// the scene's own camera, one warm-up + two timed synchronous frames per kernel, the faster counts) gives a verdict for
+// synchronous frames and one for frames in flight (choose_default_kernel: why the second has a margin), and
+// the verdicts are remembered under a hash of the scene's arrays and camera, so the other contexts of the process — the
 // frames in flight of one renderer — and the `-n` runs of a host program do not measure again.  Both kernels produce
 // the same pixels; only the rate depends on the choice.  The probe costs ~3 ms, outside benchmark()'s repeated span.
 #include <map>
@@ -435,11 +438,11 @@ static uint64_t fnv1a(uint64_t h, const void *data, size_t n)
 
 static int choose_default_kernel(r1_context *c, const r1_scene *s, const r1_camera *cam)
 {
-    c->default_variant = 4;
+    c->default_variant = c->default_variant_tp = 4;
     if (c->n_active < R1_TREE_SKIP_MIN || c->n_active >= R1_TREE_SKIP_MAX)
         return R1_OK;
     static std::mutex mu;
-    static std::map<uint64_t, int> verdicts;
+    static std::map<uint64_t, int> verdicts; // (synchronous verdict) | (throughput verdict) << 8
     uint64_t h = 0xCBF29CE484222325ull;
     const float *const src[9] = {s->center_x, s->center_y, s->center_z, s->radius_sq, s->inv_radius, s->albedo_r, s->albedo_g, s->albedo_b, s->mat_param};
     for (int k = 0; k < 9; ++k)
@@ -451,7 +454,7 @@ static int choose_default_kernel(r1_context *c, const r1_scene *s, const r1_came
         auto it = verdicts.find(h);
         if (it != verdicts.end())
         {
-            c->default_variant = it->second;
+            c->default_variant = it->second & 0xFF, c->default_variant_tp = it->second >> 8;
             return R1_OK;
         }
     }
@@ -462,6 +465,13 @@ static int choose_default_kernel(r1_context *c, const r1_scene *s, const r1_came
     int rc;
     if ((rc = ensure(c->image, (size_t)p.width * p.height * 3 + 64)) || (rc = ensure(c->counters, R1_COUNTER_BYTES + 64)))
         return rc;
+    // The latency-mode kernels of a synchronous frame are what the probe can time faithfully; frames in flight cannot be (a lone launch
+    // of the throughput kernels — a workgroup per CU, or seven frames' worth of samples in one launch — is mostly its own ramp and tail
+    // and ranked the reference's medium scene the wrong way round: 3.16 against 3.58 ms for sweep / tree where twenty frames in flight
+    // take 0.653 / 0.611 ms each).  So the synchronous probe decides both, with margins: more waves per SIMD help the tree's dependent
+    // LDS chains more than the sweep's streaming pass — on the medium scene the ratio tree / sweep is 0.99-1.03 for a synchronous frame
+    // and 0.935 in flight — so the sweep is chosen for frames in flight only where it is 8 % ahead in the probe, and for synchronous
+    // frames where it is 3 % ahead (a tie goes to the tree, which wins every other scene of the band by 10-40 %).
     double best[2] = {1e30, 1e30};
     const int kinds[2] = {R1_VARIANT_PREFILTER, R1_VARIANT_BVH};
     for (int round = 0; round < 3; ++round) // interleaved, so that a clock ramp treats both alike; round 0 warms up
@@ -476,10 +486,14 @@ static int choose_default_kernel(r1_context *c, const r1_scene *s, const r1_came
             if (round > 0 && ms < best[k])
                 best[k] = ms;
         }
-    c->default_variant = best[0] < best[1] ? 2 : 4;
+    static const int probe_log = (int)r1_knob("R1_PROBE_LOG", 0); // tuning experiments
+    if (probe_log)
+        fprintf(stderr, "r1 probe: synchronous sweep %.3f tree %.3f ms\n", best[0], best[1]);
+    c->default_variant = best[0] < 0.97 * best[1] ? 2 : 4;
+    c->default_variant_tp = best[0] < 0.92 * best[1] ? 2 : 4;
     c->tile_key_valid = false; // the caller's frames come next
     std::lock_guard<std::mutex> lock(mu);
-    verdicts[h] = c->default_variant;
+    verdicts[h] = c->default_variant | (c->default_variant_tp << 8);
     return R1_OK;
 }
 
@@ -757,7 +771,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     case R1_VARIANT_BVH: variant = 4; break;
     case R1_VARIANT_BVH_STATS: variant = 5; break;
     case R1_VARIANT_WAVEFRONT: variant = 6; break;
-    case R1_VARIANT_DEFAULT: variant = c->default_variant; break;
+    case R1_VARIANT_DEFAULT: variant = throughput_mode ? c->default_variant_tp : c->default_variant; break;
     default: variant = 2; break;
     }
     R1_HIP(hipSetDevice(c->device));
