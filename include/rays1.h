@@ -115,7 +115,8 @@ enum
 {
     R1_VARIANT_DEFAULT = 0,   /* the faster of BVH and PREFILTER for the scene: BVH, except that scenes of 9..127 hittable
                                  spheres are timed through both when they are set (r1_set_scene: a ~3 ms probe, once per
-                                 distinct scene and process; same pixels either way; r1_launch_info.kernel says which ran) */
+                                 distinct scene and process, with one verdict for synchronous frames and one for frames in
+                                 flight; same pixels either way; r1_launch_info.kernel says which ran) */
     R1_VARIANT_REFERENCE = 1, /* pass 1 in the reference's exact arithmetic (rayweek1.cpp:190-202),
                                  no prefilter; slower, used to cross-check the default       */
     R1_VARIANT_PREFILTER = 2, /* the exhaustive sweep (every ray against every sphere, as Hitable::hit does,
