@@ -13,7 +13,11 @@ reps = next((int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--reps=
 child = f"""
 import sys, statistics
 sys.path.insert(0, {ROOT!r})
+import os
 import rays1bench_amd as r1
+if os.environ.get("R1_LIB"):  # the -DR1_TUNING build reads the R1_* knobs; the shipped library reads none
+    from rays1bench_amd import binding
+    binding.set_lib_path(os.environ["R1_LIB"])
 w, h, spp = 1200, 800, 10
 rend = r1.Renderer(0); rend.set_scene(r1.create_large_scene(w, h))
 p = r1.make_params(w, h, spp, 10001, variant={variant})
