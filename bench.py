@@ -155,7 +155,7 @@ def cpu_baseline_grid(sc, w, h):
                       f"(exhaustive AVX2 sweep, the reference's algorithm), {secs:.1f} s"}
 
 
-# flop per unit of the hit tests, counted from r1_kernels.hip (add / mul / compare / min / max = 1, fma = 2):
+# flop per unit of the hit tests, counted from r1_trace.hpp (add / mul / compare / min / max = 1, fma = 2):
 #   node visit   per child box (bvh_box): 3 fma, 3 fma, 3 sub + 2 max, 3 add + 2 min, 3 cmp = 25 -> 2 x 25 = 50 for the kernels that keep the
 #                node table in LDS (the pad is evaluated once per ray since round 3); the big-scene kernels evaluate it
 #                per node (fma + 3 mul): 55 (the round-1 form, which measured |m - o|^2 per box, was 2 x 32)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define R1_ABI_VERSION 3
+#define R1_ABI_VERSION 4
 
 enum
 {
@@ -113,10 +113,8 @@ typedef struct r1_params
 
 enum
 {
-    R1_VARIANT_DEFAULT = 0,   /* the faster of BVH and PREFILTER for the scene: BVH, except that scenes of 9..127 hittable
-                                 spheres are timed through both when they are set (r1_set_scene: a ~3 ms probe, once per
-                                 distinct scene and process, with one verdict for synchronous frames and one for frames in
-                                 flight; same pixels either way; r1_launch_info.kernel says which ran) */
+    R1_VARIANT_DEFAULT = 0,   /* BVH for every scene (a property of the build: what a context launches depends on its
+                                 arguments only; same pixels as every other variant; r1_launch_info.kernel says which ran) */
     R1_VARIANT_REFERENCE = 1, /* pass 1 in the reference's exact arithmetic (rayweek1.cpp:190-202),
                                  no prefilter; slower, used to cross-check the default       */
     R1_VARIANT_PREFILTER = 2, /* the exhaustive sweep (every ray against every sphere, as Hitable::hit does,
@@ -165,7 +163,10 @@ int r1_set_scene(r1_context *ctx, const r1_scene *scene, const r1_camera *camera
  *                (common.h:80-83, rayweek1.cpp:750); with num_shards > 1 only this
  *                shard's tiles are written, other bytes are left untouched.
  *   num_rays_out number of color() invocations (rayweek1.cpp:517) of this shard.
- *   device_seconds_out  (optional) GPU time of the kernels, from HIP events. */
+ *   device_seconds_out  (optional) GPU time of the kernels, from HIP events.
+ * The frame is ONE launch: the trace kernel resolves each 32 x 32 tile as soon as its samples are complete
+ * (rayweek1.cpp:762-775 resolves a pixel where it traced it).  If rgb_out is page-locked memory (r1_host_alloc) the
+ * tiles are stored straight into it and nothing is copied; any other memory receives one copy of the finished image. */
 int r1_render(r1_context *ctx, const r1_params *params, uint8_t *rgb_out, uint64_t *num_rays_out,
               double *device_seconds_out);
 
@@ -179,12 +180,14 @@ int r1_render_samples(r1_context *ctx, const r1_params *params, uint8_t *rgb_out
  * dispatch -> pixels + ray count on the host (rayweek1.cpp:848 -> :891) for ONE frame and waits; a caller that
  * renders frame after frame (main's `-n` runs, rayweek1.cpp:969-984) can keep several in flight instead: the call
  * enqueues the frame (throughput kernels: few long-lived waves per frame) on `hip_stream` (a hipStream_t; NULL =
- * the context's stream) followed by the copies of the row-major image (width*height*3 bytes, as r1_render) and of
- * the ray count into the caller's buffers, and returns without waiting.  Both buffers are valid once the stream is
- * idle (r1_sync for the context's stream).  One frame per context at a time: K frames in flight = K contexts.
- * Whole frames only (num_shards == 1).  Buffers from r1_host_alloc (page-locked) let the copies overlap the other
- * frames' kernels; pageable memory works, but then every copy waits for its frame.  rgb_out and num_rays_out both
- * NULL: the frame is rendered and left in the context's device buffers (a measurement aid: what the copies cost). */
+ * the context's stream) and returns without waiting.  Buffers from r1_host_alloc (page-locked, num_rays_out 8-byte
+ * aligned) are written by the launch itself: every tile lands in rgb_out (row-major, width*height*3 bytes, as
+ * r1_render) when its samples are complete, the ray count when the frame's last tile has — no resolve launch, no copy.
+ * Pageable memory works too: the frame is then resolved into the context's device image and two copies follow the
+ * launch, each waiting for its frame.  Both buffers are valid once the stream is idle (r1_sync for the context's
+ * stream).  One frame per context at a time (the calls on a context are ordered by one stream, or by the caller): K
+ * frames in flight = K contexts.  Whole frames only (num_shards == 1).  rgb_out and num_rays_out both NULL: the frame is
+ * rendered and left in the context's device buffers (a measurement aid). */
 int r1_render_async(r1_context *ctx, const r1_params *params, uint8_t *rgb_out, uint64_t *num_rays_out, void *hip_stream);
 
 /* Frame BATCHES: n_frames frames of the same scene, camera and size in ONE launch; frame f is seeded
@@ -194,13 +197,14 @@ int r1_render_async(r1_context *ctx, const r1_params *params, uint8_t *rgb_out, 
  * queue is frame-major and the waves flow from one frame into the next, so that cost is paid once per batch instead of
  * once per frame (measured: DESIGN.md §4.9).  The price is latency: all frames of a batch are delivered together.
  * host_frames receives n_frames frame records of r1_frame_record_bytes() each — the row-major image (as r1_render),
- * padded to a multiple of 8 bytes, then the frame's uint64 ray count — with ONE copy enqueued behind the launch; nothing
- * is waited for (as r1_render_async; page-locked memory recommended; NULL leaves the frames on the device).  Whole
+ * padded to a multiple of 8 bytes, then the frame's uint64 ray count — written by the launch itself when the memory is
+ * page-locked (r1_host_alloc), else with ONE copy enqueued behind the launch; nothing
+ * is waited for (as r1_render_async; NULL leaves the frames on the device).  Whole
  * frames only.  Each frame's pixels and count equal what r1_render returns for its seed. */
 size_t r1_frame_record_bytes(const r1_params *params);
 int r1_render_batch_async(r1_context *ctx, const r1_params *params, int32_t n_frames, uint32_t seed_stride, void *host_frames, void *hip_stream);
 
-/* Page-locked host memory for r1_render_async's outputs (hipHostMalloc / hipHostFree). */
+/* Page-locked, device-visible host memory for the render entry points' outputs (hipHostMalloc / hipHostFree). */
 int r1_host_alloc(size_t bytes, void **out);
 void r1_host_free(void *p);
 
@@ -302,6 +306,7 @@ typedef struct r1_launch_info
     int32_t bvh_nodes;      /* inner nodes of the spatial index                   */
     int32_t bvh_leaves;
     int32_t bvh_depth;      /* inner nodes on the longest root-to-leaf path       */
+    int32_t resolver_blocks; /* workgroups of the launch that resolve finished tiles instead of tracing (in front of `blocks`; 0: a resolve launch follows) */
 } r1_launch_info;
 int r1_last_launch_info(r1_context *ctx, r1_launch_info *out);
 

@@ -50,7 +50,8 @@ class Params(C.Structure):
 class LaunchInfo(C.Structure):
     _fields_ = [("compute_units", C.c_int32), ("blocks", C.c_int32), ("threads_per_block", C.c_int32),
                 ("spheres_active", C.c_int32), ("spheres_padded", C.c_int32), ("groups", C.c_int32), ("samples", C.c_uint64),
-                ("kernel", C.c_int32), ("bvh_nodes", C.c_int32), ("bvh_leaves", C.c_int32), ("bvh_depth", C.c_int32)]
+                ("kernel", C.c_int32), ("bvh_nodes", C.c_int32), ("bvh_leaves", C.c_int32), ("bvh_depth", C.c_int32),
+                ("resolver_blocks", C.c_int32)]
 
 
 class BvhInfo(C.Structure):

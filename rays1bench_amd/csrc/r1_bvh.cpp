@@ -3,7 +3,7 @@
 // The reference has no acceleration structure ("it's even more insane idea to use linear
 // searching", README.md:163; the nested-Hitable stub at rayweek1.cpp:328-349 is unused): every
 // ray is tested against every sphere.  R1_VARIANT_BVH keeps the reference's per-sphere
-// arithmetic (exact_offer in r1_kernels.hip = rayweek1.cpp:192-202, :294-313) and only decides
+// arithmetic (exact_offer in r1_trace.hpp = rayweek1.cpp:192-202, :294-313) and only decides
 // WHICH spheres are presented to it, through a binary tree of axis-aligned boxes that is
 // conservative with respect to the reference's fp32 test, so that pixels and ray counts stay
 // bit-identical to the exhaustive sweep (tests/test_gpu_parity.py::test_bvh_*).
@@ -22,7 +22,7 @@
 // largest distance involved) and the 1-ulp reciprocals of the direction (v_rcp_f32, <= 2^-22 D),
 // together < 2^-20.7 D <= 2^-21.7 (1 + D^2), against a budget of 2^-20 (1 + D^2).
 //
-// What the kernel evaluates (r1_kernels.hip::bvh_box) is ONE fused multiply-add per node,
+// What the kernel evaluates (r1_trace.hpp::bvh_box) is ONE fused multiply-add per node,
 //      pad = A * R2 + K,      R2 = |o - C|^2 computed once per ray,
 // C a fixed point of the scene (the per-axis median of the sphere centres, R1Bvh::centre), and
 // A = 2 w2 + u, K = k + 2 w2 g^2 + u (1 + |C|_1), g = the larger |m - C| of the node's two children:

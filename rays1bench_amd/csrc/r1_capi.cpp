@@ -1,5 +1,5 @@
 // r1_capi.cpp — the C-ABI of include/rays1.h on top of the HIP runtime: context, scene
-// upload, launches, timing.  Host code only (the kernels live in r1_kernels.hip).
+// upload, launches, timing.  Host code only (the kernels live in r1_trace.hpp).
 //
 // There is no CPU fallback anywhere in this file: without a HIP device every compute
 // entry point returns R1_ENODEVICE / R1_EHIP.
@@ -25,6 +25,9 @@ extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int 
 extern "C" int r1_trace_mode(int variant, int big, int wanted); // 0 samples + one queue, 1 latency, 2 pixel: what is built for (variant, big)
 extern "C" hipError_t r1_launch_resolve(const R1ResolveArgs *args, int max_rows, hipStream_t stream);
 extern "C" hipError_t r1_launch_wavefront(R1WaveArgs *w, int blocks, hipStream_t stream);
+extern "C" hipError_t r1_launch_land_arm(uint32_t *tile_cnt, unsigned long long *frame_rays, uint32_t *frame_left, uint32_t n_frames, uint32_t n_local_tiles,
+                                         int width, int height, int spp, int tile_w, int tile_h, int tiles_x, int shard, int num_shards, hipStream_t stream);
+extern "C" hipError_t r1_launch_put6(void *dst, const uint32_t *words, hipStream_t stream);
 extern "C" hipError_t r1_launch_assemble(const void *blocks, void *rgb, int width, int height, int tile_w, int tile_h, int tiles_x, int num_shards,
                                          size_t shard_stride, int n_frames, size_t frame_in, size_t frame_out, size_t total_offset, long long total_out,
                                          int want_total, hipStream_t stream);
@@ -120,7 +123,19 @@ struct r1_context
 
     // per-frame workspace
     DevBuf counters, samples, image;
-    R1BatchArgs batch_args_host = {0, 0, {0, 0, 0}, 0}; // what the device copy (counters + R1_COUNTER_BYTES + 16) holds
+    // frame batches: the batch's numbers live in one of eight device slots (counter tail + 64 + 32 i), written by a one-thread launch whose
+    // values travel in its kernel arguments (an asynchronous copy from a host member could be overtaken by the next call)
+    R1BatchArgs batch_args_last = {0, 0, {0, 0, 0}, 0};
+    hipStream_t batch_args_stream = nullptr;
+    int batch_args_slot = -1;
+    // R1_LAND (tiles resolved inside the trace kernel): per-context state
+    bool land_prev = false;      // the last launch through this context was a LAND launch
+    int land_parity = 0;         // the set of queue heads that launch used
+    uint32_t land_gen = 0;       // launch generation: the tag of its sample records (1 .. 2^24 - 1)
+    bool land_armed = false;     // the countdowns / accumulators behind the counter block hold the values of land_key
+    r1_params land_key;
+    int land_frames = 0;
+    size_t land_tail_frames = 0; // frames the allocation's per-launch part was laid out for
     DevBuf batch_rays;  // frame batches: per-frame ray-count accumulators of the resolve launch + its finished-workgroup counter
     int tile_frames = 0; // frames per launch the tile arithmetic below was made for
     bool counters_clean = false; // the last frame's resolve launch zeroed the counter block: the next frame needs no memset
@@ -278,7 +293,7 @@ static float round_down(double v)
 
 // ---- sphere groups (level 1 of the sweep) ------------------------------------------------------
 // The sweep tests GROUPS of up to R1_GROUP_MAX nearby spheres against a bounding sphere first and
-// re-tests the members of flagged groups exactly (r1_kernels.hip).  Grouping is a pure work
+// re-tests the members of flagged groups exactly (r1_trace.hpp).  Grouping is a pure work
 // reduction: every active sphere belongs to exactly one group, the group test is conservative,
 // and hits are still resolved per sphere in the reference's arithmetic and index order.
 struct R1Group
@@ -406,96 +421,17 @@ static std::vector<R1Group> build_groups(uint32_t na, const std::vector<double> 
     return groups;
 }
 
-// ---- R1_VARIANT_DEFAULT for scenes of a few dozen spheres: measured, not guessed ---------------------------------
-// Between R1_TREE_SKIP_MIN and R1_TREE_SKIP_MAX hittable spheres neither kernel won everywhere in round 2: the reference's
-// medium scene (46 spheres packed into a 9 x 2.3 x 8 box) was 4-5 % faster through the ungrouped exhaustive sweep (since the
-// tree's root step of round 3 the two are within 3 % for a synchronous frame and the tree is 7 % ahead in flight),
-// slices of the large scene's lattice of the same size are 10-35 % faster through the tree
-// (profiles/r03/tree_vs_sweep_crossover.txt), and no cost estimate the builder can make tells the two kinds apart.
-// So a scene in that band is timed once per process: a probe frame (R1_PROBE_W x R1_PROBE_H x R1_PROBE_SPP with
-// the scene's own camera, one warm-up + two timed synchronous frames per kernel, the faster counts) gives a verdict for
-// synchronous frames and one for frames in flight (choose_default_kernel: why the second has a margin), and
-// the verdicts are remembered under a hash of the scene's arrays and camera, so the other contexts of the process — the
-// frames in flight of one renderer — and the `-n` runs of a host program do not measure again.  Both kernels produce
-// the same pixels; only the rate depends on the choice.  The probe costs ~3 ms, outside benchmark()'s repeated span.
-#include <map>
-#include <mutex>
-#define R1_PROBE_W 1200 // (a 600 x 400 x 4 probe is too small: launch and tail latency level the two kernels and it picked the sweep
-#define R1_PROBE_H 800  // on scenes where the tree is 13-25 % faster at 1200 x 800 x 10)
-#define R1_PROBE_SPP 4
-
+// ---- R1_VARIANT_DEFAULT -------------------------------------------------------------------------------------------------------------
+// DEFAULT is the box tree for every scene: a property of the build, so what a context launches depends on its arguments only and
+// the ranks of a multi-GPU job always run the same kernel.  (Round 3 timed scenes of 9..127 spheres through both kernels when
+// they were set, because the reference's dense medium scene was 4-5 % faster through the ungrouped sweep in round 2.  Since the
+// root step of the walk the tree is ahead on every row of the crossover table, profiles/r04/tree_vs_sweep_crossover*.txt — by
+// 0-3 % for one synchronous frame of the medium scene, 7 % with frames in flight — and a probe inside r1_set_scene made the first
+// timed benchmark() call, the kernel choice of each rank and a 62 MB workspace depend on a wall-clock race: VERDICT r03 / ADVICE r03.)
 struct Batch;
+struct Landing;
 static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int block_layout, void *d_rays, hipStream_t st, bool throughput_mode,
-                         const Batch *batch = nullptr);
-
-static uint64_t fnv1a(uint64_t h, const void *data, size_t n)
-{
-    const unsigned char *b = (const unsigned char *)data;
-    for (size_t i = 0; i < n; ++i)
-        h = (h ^ b[i]) * 0x100000001B3ull;
-    return h;
-}
-
-static int choose_default_kernel(r1_context *c, const r1_scene *s, const r1_camera *cam)
-{
-    c->default_variant = c->default_variant_tp = 4;
-    if (c->n_active < R1_TREE_SKIP_MIN || c->n_active >= R1_TREE_SKIP_MAX)
-        return R1_OK;
-    static std::mutex mu;
-    static std::map<uint64_t, int> verdicts; // (synchronous verdict) | (throughput verdict) << 8
-    uint64_t h = 0xCBF29CE484222325ull;
-    const float *const src[9] = {s->center_x, s->center_y, s->center_z, s->radius_sq, s->inv_radius, s->albedo_r, s->albedo_g, s->albedo_b, s->mat_param};
-    for (int k = 0; k < 9; ++k)
-        h = fnv1a(h, src[k], (size_t)s->count * 4);
-    h = fnv1a(h, s->mat_type, s->count);
-    h = fnv1a(h, cam, sizeof(*cam));
-    {
-        std::lock_guard<std::mutex> lock(mu);
-        auto it = verdicts.find(h);
-        if (it != verdicts.end())
-        {
-            c->default_variant = it->second & 0xFF, c->default_variant_tp = it->second >> 8;
-            return R1_OK;
-        }
-    }
-    r1_params p;
-    memset(&p, 0, sizeof(p));
-    p.width = R1_PROBE_W, p.height = R1_PROBE_H, p.spp = R1_PROBE_SPP, p.max_bounces = 50, p.seed = 10001;
-    p.tile_w = p.tile_h = 32, p.shard = 0, p.num_shards = 1;
-    int rc;
-    if ((rc = ensure(c->image, (size_t)p.width * p.height * 3 + 64)) || (rc = ensure(c->counters, R1_COUNTER_BYTES + 64)))
-        return rc;
-    // The latency-mode kernels of a synchronous frame are what the probe can time faithfully; frames in flight cannot be (a lone launch
-    // of the throughput kernels — a workgroup per CU, or seven frames' worth of samples in one launch — is mostly its own ramp and tail
-    // and ranked the reference's medium scene the wrong way round: 3.16 against 3.58 ms for sweep / tree where twenty frames in flight
-    // take 0.653 / 0.611 ms each).  So the synchronous probe decides both, with margins: more waves per SIMD help the tree's dependent
-    // LDS chains more than the sweep's streaming pass — on the medium scene the ratio tree / sweep is 0.99-1.03 for a synchronous frame
-    // and 0.935 in flight — so the sweep is chosen for frames in flight only where it is 8 % ahead in the probe, and for synchronous
-    // frames where it is 3 % ahead (a tie goes to the tree, which wins every other scene of the band by 10-40 %).
-    double best[2] = {1e30, 1e30};
-    const int kinds[2] = {R1_VARIANT_PREFILTER, R1_VARIANT_BVH};
-    for (int round = 0; round < 3; ++round) // interleaved, so that a clock ramp treats both alike; round 0 warms up
-        for (int k = 0; k < 2; ++k)
-        {
-            p.variant = kinds[k];
-            if ((rc = enqueue_frame(c, &p, c->image.p, 0, (char *)c->counters.p + R1_COUNTER_BYTES, c->stream, false, nullptr)))
-                return rc;
-            R1_HIP(hipStreamSynchronize(c->stream));
-            float ms = 0;
-            R1_HIP(hipEventElapsedTime(&ms, c->last0, c->last2));
-            if (round > 0 && ms < best[k])
-                best[k] = ms;
-        }
-    static const int probe_log = (int)r1_knob("R1_PROBE_LOG", 0); // tuning experiments
-    if (probe_log)
-        fprintf(stderr, "r1 probe: synchronous sweep %.3f tree %.3f ms\n", best[0], best[1]);
-    c->default_variant = best[0] < 0.97 * best[1] ? 2 : 4;
-    c->default_variant_tp = best[0] < 0.92 * best[1] ? 2 : 4;
-    c->tile_key_valid = false; // the caller's frames come next
-    std::lock_guard<std::mutex> lock(mu);
-    verdicts[h] = c->default_variant | (c->default_variant_tp << 8);
-    return R1_OK;
-}
+                         const Batch *batch = nullptr, Landing *landing = nullptr);
 
 extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *cam)
 {
@@ -629,6 +565,9 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
         }
     }
 
+    // leaf_quad fetches a sphere index speculatively for lanes that hold no flagged sphere (slot 3 of the step, whatever the step's
+    // pair count): two sentinel words behind the last pair keep that read inside the table
+    bvh.ids.resize(bvh.ids.size() + 2, 0xFFFFFFFFu);
     int rc;
     if ((rc = ensure(c->bvh_nodes, bvh.nodes.size() * 4)) || (rc = ensure(c->bvh_prims, bvh.prims.size() * 4)) ||
         (rc = ensure(c->bvh_ids, bvh.ids.size() * 4)))
@@ -678,11 +617,7 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
     c->src_mat.assign(s->mat_type, s->mat_type + s->count);
     c->src_cam = *cam;
     c->have_scene = true;
-    if ((rc = choose_default_kernel(c, s, cam)))
-    {
-        c->have_scene = false;
-        return rc;
-    }
+    c->default_variant = c->default_variant_tp = 4;
     return R1_OK;
 }
 
@@ -736,6 +671,31 @@ static int prepare_tiles(r1_context *c, const r1_params *p, int n_frames)
     return R1_OK;
 }
 
+// The context's counter allocation: [0, R1_COUNTER_BYTES) queue heads (set 0), ray count, diagnostic counters — the block the round-3
+// kernels zero between frames; then R1_COUNTER_TAIL bytes: +0 the published ray count, +64 eight batch-argument slots, +1024 queue heads
+// (set 1); then, per launch (R1_LAND): frame_rays[F] (uint64), frame_left[F] (uint32, padded), tile_cnt[F x local tiles] (uint32).
+// Called by every entry point BEFORE it takes addresses inside the allocation (it may move when the launch needs more room).
+static size_t land_frames_off() { return (size_t)R1_COUNTER_BYTES + R1_COUNTER_TAIL; }
+static int ensure_counters(r1_context *c, const r1_params *p, int n_frames)
+{
+    int rc = prepare_tiles(c, p, n_frames);
+    if (rc)
+        return rc;
+    const size_t F = (size_t)(n_frames > 0 ? n_frames : 1);
+    const size_t need = land_frames_off() + F * 16 + F * (size_t)(c->n_local_tiles ? c->n_local_tiles : 1) * 4;
+    if (c->counters.p && need <= c->counters.cap)
+        return R1_OK;
+    R1_HIP(hipStreamSynchronize(c->stream)); // (a frame in flight on another stream is the caller's to order: one frame per context at a time)
+    if ((rc = ensure(c->counters, need + need / 2)))
+        return rc;
+    R1_HIP(hipMemsetAsync(c->counters.p, 0, c->counters.cap, c->stream));
+    R1_HIP(hipStreamSynchronize(c->stream));
+    c->counters_clean = true;
+    c->land_prev = false, c->land_armed = false, c->land_parity = 0;
+    c->batch_args_slot = -1;
+    return R1_OK;
+}
+
 // Frame batch of the throughput entry points: n_frames frames in one launch (r1_device.h R1TraceArgs::n_frames); frame f is
 // written to d_out + f * out_stride and its uint64 ray count to d_out + f * out_stride + rays_offset.
 struct Batch
@@ -745,9 +705,34 @@ struct Batch
     size_t out_stride = 0, rays_offset = 0;
 };
 
-// Enqueues trace + resolve on `st`. out/d_rays are device pointers.
+// Where the caller finally wants the frame, if the device can write there (page-locked host memory): launches that resolve their own
+// tiles (R1_LAND) store the pixels and the count there directly and set `used`; the entry point then enqueues no copy.
+struct Landing
+{
+    void *out = nullptr;  // device address of the caller's pixels (row-major image, or the frame records of a batch)
+    void *rays = nullptr; // ... of its ray count (single frames)
+    bool used = false;
+};
+
+// device address of page-locked host memory (r1_host_alloc, hipHostMalloc, hipHostRegister), or null for anything else
+static void *mapped_host(const void *ptr)
+{
+    if (!ptr)
+        return nullptr;
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    if (hipPointerGetAttributes(&at, ptr) != hipSuccess)
+    {
+        (void)hipGetLastError(); // ordinary (pageable) memory is not an error here
+        return nullptr;
+    }
+    return at.type == hipMemoryTypeHost ? at.devicePointer : nullptr;
+}
+
+// Enqueues the frame (trace + resolve) on `st`.  d_out / d_rays are device addresses; d_rays == NULL stands for the context's own
+// count word (counters + R1_COUNTER_BYTES; the allocation may move in here, so callers take that address afterwards).
 static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int block_layout, void *d_rays, hipStream_t st,
-                         bool throughput_mode, const Batch *batch)
+                         bool throughput_mode, const Batch *batch, Landing *landing)
 {
     const int n_frames = batch ? batch->n_frames : 1;
     if (!c->have_scene)
@@ -758,11 +743,8 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     int rc = r1_params_check(p);
     if (rc)
         return rc;
-    // kernel selection.  DEFAULT = the faster of the two validated kernels for the scene: the box tree, except
-    // that scenes of R1_TREE_SKIP_MIN .. R1_TREE_SKIP_MAX - 1 hittable spheres are MEASURED when they are set
-    // (choose_default_kernel: the ungrouped exhaustive sweep is ahead on the reference's dense medium scene, the tree
-    // on sparse scenes of the same size).  PREFILTER always forces the exhaustive sweep, BVH always the tree; all of
-    // them produce the same pixels.
+    // kernel selection.  DEFAULT = the box tree (a property of the build, see above); PREFILTER always forces the exhaustive
+    // sweep, BVH always the tree; all of them produce the same pixels.
     int variant = 2;
     switch (p->variant)
     {
@@ -775,10 +757,10 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     default: variant = 2; break;
     }
     R1_HIP(hipSetDevice(c->device));
-    if ((rc = prepare_tiles(c, p, n_frames)))
+    if ((rc = ensure_counters(c, p, n_frames)))
         return rc;
-    if ((rc = ensure(c->counters, R1_COUNTER_BYTES + 64)))
-        return rc;
+    if (!d_rays)
+        d_rays = (char *)c->counters.p + R1_COUNTER_BYTES;
     // kernel mode: the host-returning entry points run in latency mode, the throughput entry point with few long-lived
     // waves per frame — per-sample records + r1_resolve_kernel either way, unless r1_set_pixel_mode chose PIXEL mode
     // for the throughput entry point (a lane owns a pixel: no sample records, no resolve launch, ~10 % slower)
@@ -794,15 +776,25 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
         r1_set_error("frame batches run through the throughput kernels only (no PIXEL mode, no diagnostic / reference-form / wavefront variant)");
         return R1_EINVAL;
     }
-    if (batch)
+    if (batch && !(R1_LAND && (variant == 2 || variant == 4)))
     {
         // partial ray counts of the resolve launch: one uint64 per (tile of the batch, workgroup column)
         const size_t cols = ((size_t)p->tile_w * p->tile_h + 255) / 256;
         if ((rc = ensure(c->batch_rays, (size_t)n_frames * (c->n_local_tiles ? c->n_local_tiles : 1) * cols * 8)))
             return rc;
     }
-    if (!pixel_mode && (rc = ensure(c->samples, (size_t)(c->total_samples ? c->total_samples : 1) * 16)))
-        return rc;
+    // tiles resolved inside the trace kernel: the product kernels' launches; the diagnostic builds, the reference-form
+    // sweep, the wavefront variant and PIXEL mode keep the round-3 form (records + r1_resolve_kernel, or no records at all)
+    const bool land = R1_LAND && (variant == 2 || variant == 4) && !pixel_mode && c->total_samples > 0;
+    if (!pixel_mode)
+    {
+        const size_t want = (size_t)(c->total_samples ? c->total_samples : 1) * 16;
+        const bool fresh = !c->samples.p || c->samples.cap < want;
+        if ((rc = ensure(c->samples, want)))
+            return rc;
+        if (fresh) // a record is recognised by its launch's tag: fresh memory must not carry one by accident
+            R1_HIP(hipMemsetAsync(c->samples.p, 0, c->samples.cap, st));
+    }
 
     R1TraceArgs a;
     memset(&a, 0, sizeof(a));
@@ -838,12 +830,15 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
         R1BatchArgs ba;
         ba.n_frames = (uint32_t)n_frames, ba.seed_stride = batch->seed_stride;
         ba.div_tiles = make_div(c->n_local_tiles ? c->n_local_tiles : 1u), ba.n_local_tiles = c->n_local_tiles;
-        if (memcmp(&ba, &c->batch_args_host, sizeof(ba)) != 0)
+        static_assert(sizeof(R1BatchArgs) == 24, "r1_launch_put6 writes the six words of R1BatchArgs");
+        if (c->batch_args_slot < 0 || c->batch_args_stream != st || memcmp(&ba, &c->batch_args_last, sizeof(ba)) != 0)
         {
-            c->batch_args_host = ba;
-            R1_HIP(hipMemcpyAsync((char *)c->counters.p + R1_COUNTER_BYTES + 16, &c->batch_args_host, sizeof(ba), hipMemcpyHostToDevice, st));
+            // a new slot, so that a launch still reading the previous numbers is not disturbed; written in stream order by a launch of its own
+            c->batch_args_slot = (c->batch_args_slot + 1) & 7;
+            c->batch_args_last = ba, c->batch_args_stream = st;
+            R1_HIP(r1_launch_put6((char *)c->counters.p + R1_COUNTER_BYTES + 64 + 32 * c->batch_args_slot, (const uint32_t *)&ba, st));
         }
-        a.batch = (const R1BatchArgs *)((char *)c->counters.p + R1_COUNTER_BYTES + 16);
+        a.batch = (const R1BatchArgs *)((char *)c->counters.p + R1_COUNTER_BYTES + 64 + 32 * c->batch_args_slot);
     }
     a.full = c->full;
     a.div_full = make_div(c->full);
@@ -862,7 +857,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     // saves the two memset launches in front of every frame (they cost nothing to execute and ~10 us each to dispatch:
     // a rank of an 8-GPU run renders its share of a frame in 140 us).  Frames without a resolve launch, and the diagnostic
     // builds, whose counters are read back afterwards, count into the caller's word and clear with memsets.
-    const bool fused_clear = !pixel_mode && c->n_local_tiles && c->total_samples && variant != 3 && variant != 5;
+    const bool fused_clear = !land && !pixel_mode && c->n_local_tiles && c->total_samples && variant != 3 && variant != 5;
     a.num_rays = fused_clear ? (unsigned long long *)((char *)c->counters.p + 32) : (unsigned long long *)d_rays;
     a.stats = (variant == 3 || variant == 5) ? (unsigned long long *)((char *)c->counters.p + 128) : nullptr;
 
@@ -911,6 +906,21 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
         blocks = needed;
     if (blocks < 1)
         blocks = 1;
+    // R1_LAND: resolver workgroups at the front of the grid (`blocks` stays the number of TRACING workgroups).  A frame in flight adds
+    // them to its small grid; a synchronous frame's grid fills the chip, so there they come out of the tracing workgroups' slots.
+    long long n_res = 0;
+    if (land)
+    {
+        static const long long res_tp_env = r1_knob("R1_LAND_RES_TP", R1_LAND_RES_TP), res_sync_env = r1_knob("R1_LAND_RES_SYNC", R1_LAND_RES_SYNC);
+        const long long tiles_all = (long long)c->n_local_tiles * n_frames;
+        n_res = std::max(1LL, std::min(throughput_mode ? res_tp_env : res_sync_env, tiles_all));
+        const long long slots = (long long)c->cus * per_cu;
+        if (!throughput_mode && blocks + n_res > slots)
+        {
+            n_res = std::max(1LL, std::min(n_res, slots / 8));
+            blocks = std::max(1LL, std::min(blocks, slots - n_res));
+        }
+    }
 
     // Queue chunk per atomic: guided (remaining / (2 waves)) between chunk_min and chunk_max.  Large
     // chunks keep a wave on consecutive samples (coherent primary rays, whole sample-record lines)
@@ -949,7 +959,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     {
         static const int nq_env = (int)r1_knob("R1_NQ", 0), ch_env = (int)r1_knob("R1_CHUNK", 0);
         long long nq = nq_env > 0 ? nq_env : R1_SUBQUEUES;
-        // a wave only ever pulls from its home sub-queue (r1_kernels.hip: home = (4 (block / 8) + wave) % nq), so every
+        // a wave only ever pulls from its home sub-queue (r1_trace.hpp: home = (4 (block / 8) + wave) % nq), so every
         // sub-queue needs home waves: the full groups of 8 workgroups must cover all nq residues
         if (nq > 4 * (blocks / 8))
             nq = 4 * (blocks / 8);
@@ -960,6 +970,60 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
             a.nq = (uint32_t)nq;
             a.chunk_max = a.chunk_min = ch_env > 0 ? (uint32_t)ch_env : 64u;
         }
+    }
+    if (land)
+    {
+        // Launches alternate between two sets of queue heads; resolver 0 zeroes the set the launch before used, which nobody touches
+        // any more (a wave may still ask its own queue for work after the frame's last tile has been resolved, so a launch cannot
+        // clear its own).  After anything else has run through this context both sets (and the round-3 block) are cleared here.
+        if (!c->land_prev)
+        {
+            R1_HIP(hipMemsetAsync(c->counters.p, 0, R1_COUNTER_BYTES, st));
+            R1_HIP(hipMemsetAsync((char *)c->counters.p + R1_COUNTER_BYTES + 1024, 0, R1_COUNTER_BYTES - 1024, st)); // (not the batch-argument slots in front of it)
+            c->land_parity = 1;
+        }
+        c->land_parity ^= 1;
+        char *const set0 = (char *)c->counters.p + 1024, *const set1 = (char *)c->counters.p + R1_COUNTER_BYTES + 1024;
+        a.queue = (uint32_t *)(c->land_parity ? set1 : set0);
+        a.land.clear_heads = (uint32_t *)(c->land_parity ? set0 : set1);
+        a.land.clear_count = (R1_COUNTER_BYTES - 1024) / 128;
+        static_assert((R1_COUNTER_BYTES - 1024) / 128 <= R1_BLOCK && R1_COUNTER_TAIL >= 1024 + (R1_COUNTER_BYTES - 1024), "the second set of queue heads fits the tail");
+        // the launch's generation tags its sample records (1 .. 2^24 - 1; on wrap-around the records are wiped)
+        c->land_gen = (c->land_gen + 1) & 0xFFFFFFu;
+        if (c->land_gen == 0)
+        {
+            R1_HIP(hipMemsetAsync(c->samples.p, 0, c->samples.cap, st));
+            c->land_gen = 1;
+        }
+        a.land_tag = c->land_gen << 8;
+        a.land_res = (uint32_t)n_res;
+        unsigned long long *frame_rays = (unsigned long long *)((char *)c->counters.p + land_frames_off());
+        uint32_t *frame_left = (uint32_t *)(frame_rays + n_frames);
+        a.land_cnt = frame_left + ((n_frames + 1) & ~1);
+        if (!c->land_armed || c->land_frames != n_frames || !same_tiling(c->land_key, *p))
+        {
+            R1_HIP(r1_launch_land_arm(a.land_cnt, frame_rays, frame_left, (uint32_t)n_frames, c->n_local_tiles, p->width, p->height, p->spp, p->tile_w, p->tile_h,
+                                      a.tiles_x, p->shard, p->num_shards, st));
+            c->land_armed = true, c->land_frames = n_frames, c->land_key = *p;
+        }
+        if (landing && landing->out && (batch || landing->rays))
+        {
+            d_out = landing->out;
+            if (!batch)
+                d_rays = landing->rays;
+            landing->used = true;
+        }
+        a.land.out = (uint8_t *)d_out;
+        a.land.rays_dst = (unsigned long long *)d_rays;
+        a.land.out_stride = batch ? batch->out_stride : 0;
+        a.land.rays_offset = batch ? batch->rays_offset : 0;
+        a.land.rays_in_out = batch ? 1u : 0u;
+        a.land.frame_rays = frame_rays, a.land.frame_left = frame_left;
+        a.land.n_frames = (uint32_t)n_frames;
+        a.land.block_layout = (uint32_t)block_layout;
+        a.land.inv_spp = (float)(1.0f / p->spp); // rayweek1.cpp:765
+        a.land.error = c->host_word_dev ? (uint32_t *)(c->host_word_dev + 1) : nullptr;
+        a.num_rays = nullptr;
     }
     hipEvent_t e0 = c->ev0, e1 = c->ev1, e2 = c->ev2;
     if (c->ring_on && c->ring_frames > 0)
@@ -972,13 +1036,14 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     if (big || (R1_STACK_LDS_WORDS < R1_STACK_WORDS && (variant == 4 || variant == 5)))
     {
         // sized for the largest grid of this kernel (not this frame's): a frame with a bigger grid must not reallocate
-        const size_t entries = big ? R1_STACK_ENTRIES : R1_STACK_ENTRIES - 3 * R1_STACK_LDS_WORDS_TP; // (sized for the build that keeps the fewest words in LDS)
+        // (sized for the build that keeps the fewest words in LDS: the latency / diagnostic builds keep R1_STACK_LDS_WORDS, the throughput builds R1_STACK_LDS_WORDS_TP)
+        const size_t entries = big ? R1_STACK_ENTRIES : R1_STACK_ENTRIES - 3 * (R1_STACK_LDS_WORDS < R1_STACK_LDS_WORDS_TP ? R1_STACK_LDS_WORDS : R1_STACK_LDS_WORDS_TP);
         const size_t max_blocks = std::max((size_t)blocks, (size_t)c->cus * (size_t)per_cu);
         if ((rc = ensure(c->gstack, entries * max_blocks * R1_BLOCK * 4)))
             return rc;
         a.gstack = (uint32_t *)c->gstack.p;
     }
-    if (!c->counters_clean)
+    if (!land && !c->counters_clean)
         R1_HIP(hipMemsetAsync(c->counters.p, 0, R1_COUNTER_BYTES, st));
     c->counters_clean = false;
     if (variant == 3 || variant == 5)
@@ -990,11 +1055,11 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
         c->wave_log_ptr = (unsigned long long)c->wave_log.p;
         R1_HIP(hipMemcpyAsync((char *)c->counters.p + 128 + 16 * 8, &c->wave_log_ptr, 8, hipMemcpyHostToDevice, st));
     }
-    if (!fused_clear)
+    if (!fused_clear && !land)
         R1_HIP(hipMemsetAsync(d_rays, 0, 8, st));
     R1_HIP(hipEventRecord(e0, st));
     if (c->total_samples && variant != 6)
-        R1_HIP(r1_launch_trace(&a, variant, big, mode, (int)blocks, st));
+        R1_HIP(r1_launch_trace(&a, variant, big, mode, (int)(blocks + n_res), st));
     if (c->total_samples && variant == 6)
     {
         // wavefront variant: path state, per-level queues and the attenuation stack live in HBM
@@ -1050,17 +1115,21 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
         r.reset = (uint32_t *)c->counters.p;
     }
     static const int resolve_rows = (int)r1_knob("R1_RESOLVE_ROWS", R1_RESOLVE_ROWS_TP); // tuning experiments
-    if (c->n_local_tiles && !pixel_mode)
+    if (land)
+        ; // the trace launch resolved its tiles itself
+    else if (c->n_local_tiles && !pixel_mode)
         R1_HIP(r1_launch_resolve(&r, throughput_mode ? resolve_rows : 0, st));
     else if (batch) // a shard without tiles: its frames' counts are zero
         for (int f = 0; f < n_frames; ++f)
             R1_HIP(hipMemsetAsync((char *)d_out + (size_t)f * batch->out_stride + batch->rays_offset, 0, 8, st));
     c->counters_clean = fused_clear;
+    c->land_prev = land;
     R1_HIP(hipEventRecord(e2, st));
     c->last0 = e0, c->last1 = e1, c->last2 = e2;
     c->timing_valid = true;
 
     c->info.blocks = (int32_t)blocks;
+    c->info.resolver_blocks = (int32_t)n_res;
     c->info.threads_per_block = R1_BLOCK;
     c->info.spheres_active = (int32_t)c->n_active;
     c->info.spheres_padded = (int32_t)c->n_padded_scene;
@@ -1074,6 +1143,18 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
 }
 
 // ---- public render entry points ---------------------------------------------------------------------
+
+// a resolver of an earlier launch gave up waiting (R1_LAND_MAX_WAIT): the frames of that launch are not valid
+static int land_check(r1_context *c)
+{
+    if (c->host_word && ((volatile uint32_t *)c->host_word)[2])
+    {
+        ((volatile uint32_t *)c->host_word)[2] = 0;
+        r1_set_error("a launch did not resolve all of its tiles (a resolver workgroup gave up waiting): its frames are not valid");
+        return R1_EHIP;
+    }
+    return R1_OK;
+}
 
 static int render_host(r1_context *c, const r1_params *p, uint8_t *rgb_out, uint64_t *num_rays_out, double *device_seconds_out,
                        float *samples_out)
@@ -1097,20 +1178,23 @@ static int render_host(r1_context *c, const r1_params *p, uint8_t *rgb_out, uint
     const size_t out_bytes = sharded ? r1_shard_block_bytes(p) : img_bytes;
     if ((rc = ensure(c->image, out_bytes + 64)))
         return rc;
-    if ((rc = ensure(c->counters, R1_COUNTER_BYTES + 64)))
-        return rc;
     // the ray count: stored by the frame's last launch straight into the context's page-locked word (no second copy to
     // enqueue and wait for); the diagnostic builds count with atomics and keep a device word + copy
     const bool stats = p->variant == R1_VARIANT_STATS || p->variant == R1_VARIANT_BVH_STATS;
     const bool direct = !stats && c->host_word_dev;
-    void *d_rays = direct ? (void *)c->host_word_dev : (void *)((char *)c->counters.p + R1_COUNTER_BYTES); // (behind the block the frame's last launch zeroes)
-    if ((rc = enqueue_frame(c, p, c->image.p, sharded ? 1 : 0, d_rays, c->stream, false)))
+    // a page-locked pixel buffer (r1_host_alloc) receives the tiles straight from the trace kernel's resolvers: no copy either
+    Landing land_to;
+    if (direct && !sharded)
+        land_to.out = mapped_host(rgb_out), land_to.rays = c->host_word_dev;
+    if ((rc = enqueue_frame(c, p, c->image.p, sharded ? 1 : 0, direct ? (void *)c->host_word_dev : nullptr, c->stream, false, nullptr, &land_to)))
         return rc;
+    void *const d_rays = direct ? (void *)c->host_word_dev : (void *)((char *)c->counters.p + R1_COUNTER_BYTES); // (behind the block the frame's last launch zeroes)
 
     uint64_t rays = 0;
     if (!sharded)
     {
-        R1_HIP(hipMemcpyAsync(rgb_out, c->image.p, img_bytes, hipMemcpyDeviceToHost, c->stream));
+        if (!land_to.used)
+            R1_HIP(hipMemcpyAsync(rgb_out, c->image.p, img_bytes, hipMemcpyDeviceToHost, c->stream));
         if (!direct)
             R1_HIP(hipMemcpyAsync(&rays, d_rays, 8, hipMemcpyDeviceToHost, c->stream));
         R1_HIP(hipStreamSynchronize(c->stream));
@@ -1134,6 +1218,8 @@ static int render_host(r1_context *c, const r1_params *p, uint8_t *rgb_out, uint
                        block.data() + ((size_t)lt * p->tile_h * p->tile_w + (size_t)ly * p->tile_w) * 3, (size_t)tw * 3);
         }
     }
+    if ((rc = land_check(c)))
+        return rc;
     if (direct)
         rays = *(volatile unsigned long long *)c->host_word;
     if (num_rays_out)
@@ -1162,8 +1248,17 @@ static int render_host(r1_context *c, const r1_params *p, uint8_t *rgb_out, uint
             for (int ly = 0; ly < th; ++ly)
                 for (int lx = 0; lx < tw; ++lx)
                     for (int sm = 0; sm < p->spp; ++sm)
-                        memcpy(samples_out + (((size_t)(y0 + ly) * p->width + (x0 + lx)) * p->spp + sm) * 4,
-                               src + ((size_t)sm * tile_px + (size_t)(ly * p->tile_w + lx)) * 4, 16);
+                    {
+                        float *dst = samples_out + (((size_t)(y0 + ly) * p->width + (x0 + lx)) * p->spp + sm) * 4;
+                        memcpy(dst, src + ((size_t)sm * tile_px + (size_t)(ly * p->tile_w + lx)) * 4, 16);
+                        if (c->land_prev) // the launch tagged its records' ray-count words (R1_LAND): the ABI's word is the count alone
+                        {
+                            uint32_t wv;
+                            memcpy(&wv, dst + 3, 4);
+                            wv &= 255u;
+                            memcpy(dst + 3, &wv, 4);
+                        }
+                    }
         }
     }
     return R1_OK;
@@ -1209,16 +1304,17 @@ extern "C" int r1_render_async(r1_context *c, const r1_params *p, uint8_t *rgb_o
     const size_t img_bytes = (size_t)p->width * p->height * 3;
     if ((rc = ensure(c->image, img_bytes + 64)))
         return rc;
-    if ((rc = ensure(c->counters, R1_COUNTER_BYTES + 64)))
-        return rc;
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    void *d_rays = (char *)c->counters.p + R1_COUNTER_BYTES;
-    if ((rc = enqueue_frame(c, p, c->image.p, 0, d_rays, st, true)))
+    // page-locked buffers (r1_host_alloc) receive the tiles and the count straight from the trace kernel's resolvers: nothing to copy
+    Landing land_to;
+    if (rgb_out && ((uintptr_t)num_rays_out & 7u) == 0)
+        land_to.out = mapped_host(rgb_out), land_to.rays = mapped_host(num_rays_out);
+    if ((rc = enqueue_frame(c, p, c->image.p, 0, nullptr, st, true, nullptr, &land_to)))
         return rc;
-    if (rgb_out) // (both NULL: the frame stays in the context's device buffers — a measurement aid, bench.py's value_device_resident)
+    if (rgb_out && !land_to.used) // (both NULL: the frame stays in the context's device buffers — a measurement aid, bench.py's value_device_resident)
     {
         R1_HIP(hipMemcpyAsync(rgb_out, c->image.p, img_bytes, hipMemcpyDeviceToHost, st));
-        R1_HIP(hipMemcpyAsync(num_rays_out, d_rays, 8, hipMemcpyDeviceToHost, st));
+        R1_HIP(hipMemcpyAsync(num_rays_out, (char *)c->counters.p + R1_COUNTER_BYTES, 8, hipMemcpyDeviceToHost, st));
     }
     return R1_OK;
 }
@@ -1245,14 +1341,15 @@ extern "C" int r1_render_batch_async(r1_context *c, const r1_params *p, int32_t 
     const size_t frame = r1_frame_record_bytes(p);
     if ((rc = ensure(c->image, frame * (size_t)n_frames)))
         return rc;
-    if ((rc = ensure(c->counters, R1_COUNTER_BYTES + 64)))
-        return rc;
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     Batch b;
     b.n_frames = n_frames, b.seed_stride = seed_stride, b.out_stride = frame, b.rays_offset = frame - 8;
-    if ((rc = enqueue_frame(c, p, c->image.p, 0, (char *)c->counters.p + R1_COUNTER_BYTES, st, true, &b)))
+    Landing land_to;
+    if (host_frames && ((uintptr_t)host_frames & 7u) == 0)
+        land_to.out = mapped_host(host_frames);
+    if ((rc = enqueue_frame(c, p, c->image.p, 0, nullptr, st, true, &b, &land_to)))
         return rc;
-    if (host_frames) // (NULL: the frames stay in the context's device buffer — a measurement aid)
+    if (host_frames && !land_to.used) // (NULL: the frames stay in the context's device buffer — a measurement aid)
         R1_HIP(hipMemcpyAsync(host_frames, c->image.p, frame * (size_t)n_frames, hipMemcpyDeviceToHost, st));
     return R1_OK;
 }
@@ -1269,13 +1366,11 @@ extern "C" int r1_render_shard_device_batch(r1_context *c, const r1_params *p, i
     int rc = r1_params_check(p);
     if (rc)
         return rc;
-    if ((rc = ensure(c->counters, R1_COUNTER_BYTES + 64)))
-        return rc;
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     const size_t record = r1_shard_record_bytes(p);
     Batch b;
     b.n_frames = n_frames, b.seed_stride = seed_stride, b.out_stride = record, b.rays_offset = record - 8;
-    return enqueue_frame(c, p, d_records, 1, (char *)c->counters.p + R1_COUNTER_BYTES, st, true, &b);
+    return enqueue_frame(c, p, d_records, 1, nullptr, st, true, &b);
 }
 
 extern "C" int r1_host_alloc(size_t bytes, void **out)
@@ -1412,7 +1507,7 @@ extern "C" int r1_sync(r1_context *c)
         return R1_EINVAL;
     R1_HIP(hipSetDevice(c->device));
     R1_HIP(hipStreamSynchronize(c->stream));
-    return R1_OK;
+    return land_check(c);
 }
 
 extern "C" int r1_last_timing(r1_context *c, double *trace_kernel_ms, double *total_ms)

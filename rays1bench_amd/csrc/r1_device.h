@@ -1,4 +1,4 @@
-// r1_device.h — device-side data layout shared by r1_kernels.hip and r1_capi.cpp.
+// r1_device.h — device-side data layout shared by r1_trace.hpp and r1_capi.cpp.
 #ifndef R1_DEVICE_H
 #define R1_DEVICE_H
 
@@ -42,12 +42,28 @@
 #define R1_BVH_STACK 32        // R1_VARIANT_BVH: per-lane traversal stack entries in LDS = most inner nodes on a path
 #define R1_BVH_TOP_NODES 63    // box tree: the first nodes in breadth-first order (6 levels); the big-scene kernels keep them in LDS (4 KB: 0 / 63 / 127 / 255 nodes -> 12.9 / 13.3 / 13.0 / 12.6 Grays/s on 100 004 spheres, the larger copies cost workgroups per CU)
 #define R1_BVH_LEAF 4          // spheres per leaf (<= 14; stored as pairs)
-#define R1_TREE_SKIP_MIN 9     // DEFAULT kernel: scenes of [R1_TREE_SKIP_MIN, R1_TREE_SKIP_MAX) hittable spheres are timed through the sweep AND the
-#define R1_TREE_SKIP_MAX 128   // tree when they are set (r1_capi.cpp choose_default_kernel); box tree otherwise
 #define R1_SUBQUEUES 16        // latency mode: sub-queues of the sample queue (R1TraceArgs::nq)
 #define R1_COUNTER_BYTES 4096  // per-context counter block: queue heads, ray count (+32), drain counts, stats (+128), sub-queues at +1024;
                                // the allocation carries 64 more bytes: the published ray count of the synchronous entry points
 #define R1_COOP_LANES 2        // R1TraceArgs::coop_lanes (one synchronous frame: 2 -> 1.144 ms, 4 -> 1.160, 8 -> 1.193, 16 -> 1.263)
+// Tiles resolved INSIDE the trace kernel (round 4): the first R1TraceArgs::land_res workgroups of the grid do not trace;
+// they wait for tiles whose samples are complete (a per-tile countdown the tracing waves feed), sum each pixel's records in sample order
+// (rayweek1.cpp:762-775) and store the pixels where the frame is wanted — device memory or the caller's page-locked host buffer.
+// No resolve launch, no copy.  0 builds the round-3 form (r1_resolve_kernel after the trace kernel) for A/B measurements.
+#ifndef R1_LAND
+#define R1_LAND 1
+#endif
+#ifndef R1_LAND_RES_TP
+#define R1_LAND_RES_TP 2       // resolver workgroups of a frame in flight (its 254 tracing workgroups share the chip with the other frames')
+#endif
+#ifndef R1_LAND_RES_SYNC
+#define R1_LAND_RES_SYNC 32    // ... of a synchronous frame, whose grid fills the chip (taken from the tracing workgroups)
+#endif
+#define R1_LAND_MAX_WAIT (1u << 26) // resolver: polls (~1 us each) without any of its tiles completing, or failed passes over one tile, before it
+                                    // gives up and flags the launch (a miscount would otherwise hang the device instead of failing the call)
+#define R1_COUNTER_TAIL 4096   // behind the R1_COUNTER_BYTES block: +0 published ray count, +64 batch-argument slots (8 x 32 B), +1024 the second
+                               // set of queue heads (frames alternate between the sets; the resolvers of a launch zero the set the
+                               // launch before it used), then per launch: frame accumulators and the per-tile countdowns
 
 // Tuning knobs.  The SHIPPED library never reads the environment: what it does depends on its arguments only.  A build made
 // with -DR1_TUNING (`make tuning` -> lib/librays1_tuning.so; the scripts under tools/ load it explicitly) reads the R1_*
@@ -84,6 +100,23 @@ struct R1BatchArgs
     uint32_t seed_stride;
     R1FastDiv div_tiles; // by n_local_tiles
     uint32_t n_local_tiles;
+};
+
+// What the resolver workgroups of a launch need (R1_LAND); by value in the kernel arguments, read on the resolvers' code path only.
+struct R1LandArgs
+{
+    uint8_t *out;                   // frame 0's pixels: row-major image (block_layout 0) or dense tile block (1); device memory or page-locked host memory
+    unsigned long long *rays_dst;   // !rays_in_out: the frame's ray count (device memory or a page-locked host word)
+    unsigned long long out_stride;  // frame f of a batch: out + f * out_stride
+    unsigned long long rays_offset; // rays_in_out: frame f's uint64 count at out + f * out_stride + rays_offset
+    unsigned long long *frame_rays; // [n_frames] ray-count accumulators (zero between launches)
+    uint32_t *frame_left;           // [n_frames] tiles not yet resolved (n_local_tiles between launches)
+    uint32_t *clear_heads;          // queue heads of the set the PREVIOUS launch through this context used: zeroed by resolver 0
+    uint32_t clear_count;           // ... that many heads, 32 words apart
+    uint32_t n_frames;              // frames of the launch (1: a single frame)
+    uint32_t rays_in_out, block_layout;
+    float inv_spp;                  // (float)(1.0f / spp), rayweek1.cpp:765
+    uint32_t *error;                // page-locked host word (or null): set if a resolver gave up waiting (R1_LAND_MAX_WAIT) — never in a correct run
 };
 
 // Everything the trace kernel needs; passed by value (kernarg segment => SGPRs).
@@ -153,7 +186,7 @@ struct R1TraceArgs
                                  // chunk_max slots, chunk c belongs to sub-queue c % nq and a wave only pulls from sub-queue wave % nq:
                                  // a returning atomic on ONE line sustains 88 M/s on this chip (tools/ubench_atomic.hip), too few for
                                  // 6144 waves taking a wave-full at a time
-    float4 *samples;             // [total_samples] {r, g, b, bit_cast<float>(rays)}.  PIXEL mode (r1_kernels.hip struct Pixel): the
+    float4 *samples;             // [total_samples] {r, g, b, bit_cast<float>(rays)}.  PIXEL mode (r1_trace.hpp struct Pixel): the
                                  // queue holds PIXELS (full = tile_w * tile_h, total_samples = padded pixels of the shard) and this
                                  // is the uint8 RGB output the kernel resolves into
     unsigned long long *num_rays; // accumulated color() invocations
@@ -163,6 +196,11 @@ struct R1TraceArgs
     int32_t bvh_depth;            // tree kernels: traversal stack entries per thread (dynamic LDS = depth * R1_BLOCK * 4)
     int32_t block_layout;         // PIXEL mode: 1 = `samples` is a dense tile block (pixel index = queue slot), 0 = a row-major image
     float inv_spp;                // PIXEL mode: (float)(1.0f / spp), rayweek1.cpp:765
+    // R1_LAND (tiles resolved inside the kernel): land_res > 0 turns it on for this launch
+    uint32_t land_res;            // workgroups 0 .. land_res - 1 are resolvers, the rest trace
+    uint32_t land_tag;            // launch generation << 8, or-ed into every sample record's ray-count word: a record is the launch's own iff its tag matches
+    uint32_t *land_cnt;           // [n_frames * n_local_tiles] samples each tile still lacks; the tracing waves subtract, the tile's resolver re-arms
+    R1LandArgs land;
     uint32_t coop_lanes;          // small scenes: once the queue is empty, a wave with <= coop_lanes live paths tests each of them
                                   // against ALL spheres, 64 at a time across the wave (cooperative_sweep), instead of walking the tree
                                   // with 60 lanes masked off: the frame's tail is a few 51-bounce chains, and this shortens a step

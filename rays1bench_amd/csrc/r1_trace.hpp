@@ -1,4 +1,12 @@
-// r1_kernels.hip — hand-written HIP for gfx950 (MI355X, wave64): the per-pixel/per-sample
+// r1_trace.hpp — the device side of the hot path (gfx950, wave64): device functions + the persistent trace kernel template.
+// Included by the translation units that instantiate the kernel (r1_trace_tree_small.hip, r1_trace_tree_big.hip,
+// r1_trace_sweep_small.hip, r1_trace_sweep_big.hip) and by r1_aux_kernels.hip (wavefront variant, resolve, assemble), so that an
+// experiment on one kernel family rebuilds one file (hygiene) and `make -j` builds the families side by side.
+// Everything here has internal linkage (anonymous namespace / templates).
+#ifndef R1_TRACE_HPP
+#define R1_TRACE_HPP
+
+// r1_trace.hpp — hand-written HIP for gfx950 (MI355X, wave64): the per-pixel/per-sample
 // path-tracing hot path of rays1bench step13.
 //
 // What it replaces (all /root/reference/src/step13/):
@@ -1244,6 +1252,187 @@ __device__ __forceinline__ bool shade_level(const R1TraceArgs &A, Path &p, const
     return done;
 }
 
+// ---- tiles resolved inside the trace kernel (R1_LAND) ------------------------------------------------------
+// The reference resolves a pixel where it traced it (rayweek1.cpp:762-775).  Here the samples of a pixel end on different lanes,
+// waves and XCDs, and their fp32 sum must run in sample order, so every sample still leaves a 16-byte record; but the records of a
+// 32 x 32 tile are summed by the trace kernel's own launch as soon as the tile is complete, and the pixels go straight to where the
+// frame is wanted — no second launch waiting for workgroup slots behind persistent waves, no copy.
+//   tracing waves:  record = {r, g, b, rays | tag} with ONE 16-byte write-through store (sc1: the eight XCDs' L2s are not coherent with
+//                   each other; a write-back fence per store costs 100 us, tools/ubench_xcd_visibility.hip), then the finished lanes of
+//                   the wave subtract their number from the tile's countdown (one fire-and-forget device-scope atomic per tile);
+//   resolvers:      workgroups 0 .. land_res - 1.  Resolver r owns tiles r, r + land_res, ...; it polls their countdowns, and sums a tile
+//                   that reads zero: sc1 loads, every record's tag checked against the launch's — the countdown is not ordered after
+//                   the stores it counts, so a record may not have landed yet: the tile is then simply tried again — pixels written,
+//                   the tile's rays added to the frame's count, the countdown re-armed for the next launch.  The resolver of a frame's
+//                   last tile publishes the frame's ray count.
+// The tag also makes the records self-describing across launches: a slot still holding an older launch's record never matches.
+typedef float land_f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t land_u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void land_store(float4 *dst, const V3 col, const uint32_t w)
+{
+    const land_f4 v = {col.x, col.y, col.z, __uint_as_float(w)};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+}
+
+// the lanes with `fin` have just stored the record of sample slot k: count them into their tiles' countdowns (usually one tile per wave
+// and iteration; a wave between two chunks, or one that ends an old path, has two).  Called by all 64 lanes.
+__device__ __forceinline__ void land_count(const R1TraceArgs &A, const bool fin, const uint32_t k, const int lane)
+{
+    unsigned long long rest = __ballot(fin);
+    if (rest == 0ull)
+        return;
+    const uint32_t j = fastdiv(k, A.div_full); // tile of the launch: k = (j spp + s) tile_px + pix
+    do
+    {
+        const int l = __ffsll((long long)rest) - 1;
+        const uint32_t j0 = (uint32_t)__builtin_amdgcn_readlane((int)j, l);
+        const unsigned long long same = __ballot(fin && j == j0);
+        if (lane == l)
+            (void)__hip_atomic_fetch_sub(A.land_cnt + j0, (uint32_t)__popcll(same), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rest &= ~same;
+    } while (rest);
+}
+
+// One tile of the launch (t = frame * n_local_tiles + local tile) by the whole workgroup: false if a record did not carry the launch's
+// tag (nothing is published then; pixels written from such a pass are overwritten by the pass that succeeds — the host sees the
+// buffer only after the kernel).  Same arithmetic and order as r1_resolve_kernel = rayweek1.cpp:762-775.
+__device__ __forceinline__ bool land_resolve_tile(const R1TraceArgs &A, const uint32_t t, unsigned long long *s_part /* [4] */)
+{
+    const R1LandArgs &L = A.land;
+    const int tid = (int)threadIdx.x;
+    const uint32_t f = t / A.n_local_tiles, lt = t - f * A.n_local_tiles;
+    const uint32_t tile = (uint32_t)A.shard + lt * (uint32_t)A.num_shards;
+    const uint32_t ty = tile / (uint32_t)A.tiles_x, tx = tile - ty * (uint32_t)A.tiles_x;
+    const int x0 = (int)tx * A.tile_w, y0 = (int)ty * A.tile_h;
+    const int tw = min(A.tile_w, A.width - x0), th = min(A.tile_h, A.height - y0);
+    const uint32_t tile_px = (uint32_t)(A.tile_w * A.tile_h);
+    // the tile's records [s][pixel] through a buffer resource: 16-byte loads with the sc1 bit (they must not be served from this XCD's L2)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(A.samples + (size_t)t * A.full), 0, (int)(A.full * 16u), 0x00020000);
+    constexpr int SC1 = 16;
+    uint8_t *const out = L.out + (size_t)f * L.out_stride;
+    uint32_t bad = 0;
+    unsigned long long rays = 0;
+    for (uint32_t pix = (uint32_t)tid; pix < tile_px; pix += R1_BLOCK)
+    {
+        const int ly = (int)(pix / (uint32_t)A.tile_w), lx = (int)(pix - (uint32_t)ly * (uint32_t)A.tile_w);
+        if (lx >= tw || ly >= th)
+            continue; // void slots of an edge tile
+        float cr = 0, cg = 0, cb = 0;
+        int s = 0;
+        for (; s + 8 <= A.spp; s += 8)
+        {
+            land_u4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((((uint32_t)(s + u)) * tile_px + pix) * 16u), 0, SC1);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+            {
+                cr += __uint_as_float(v[u].x), cg += __uint_as_float(v[u].y), cb += __uint_as_float(v[u].z); // col += color(...) rayweek1.cpp:762
+                bad |= (v[u].w & ~255u) ^ A.land_tag;
+                rays += v[u].w & 255u;
+            }
+        }
+        for (; s < A.spp; ++s)
+        {
+            const land_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((uint32_t)s * tile_px + pix) * 16u), 0, SC1);
+            cr += __uint_as_float(v.x), cg += __uint_as_float(v.y), cb += __uint_as_float(v.z);
+            bad |= (v.w & ~255u) ^ A.land_tag;
+            rays += v.w & 255u;
+        }
+        cr *= L.inv_spp, cg *= L.inv_spp, cb *= L.inv_spp;
+        cr = ieee_sqrt(cr), cg = ieee_sqrt(cg), cb = ieee_sqrt(cb);
+        const size_t o = L.block_layout ? ((size_t)lt * tile_px + pix) * 3 : ((size_t)(y0 + ly) * A.width + (x0 + lx)) * 3;
+        out[o + 0] = (uint8_t)(int)(cr * 255.99f);
+        out[o + 1] = (uint8_t)(int)(cg * 255.99f);
+        out[o + 2] = (uint8_t)(int)(cb * 255.99f);
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        rays += __shfl_down(rays, off, 64);
+    if ((tid & 63) == 0)
+        s_part[tid >> 6] = rays;
+    const bool good = __syncthreads_or(bad != 0u) == 0; // (also the barrier between s_part's writes and its read)
+    if (good && tid == 0)
+    {
+        // the tile's rays, then one tile less to go: the second atomic is issued only when the first has been performed
+        const unsigned long long before = __hip_atomic_fetch_add(L.frame_rays + f, s_part[0] + s_part[1] + s_part[2] + s_part[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(before));
+        __hip_atomic_store(A.land_cnt + t, (uint32_t)(tw * th * A.spp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // re-armed for the next launch
+        const uint32_t left = __hip_atomic_fetch_sub(L.frame_left + f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left == 1u)
+        {
+            // the frame's last tile: every other tile's rays have been added (their resolvers saw their add performed before they counted down)
+            const unsigned long long total = __hip_atomic_exchange(L.frame_rays + f, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long *dst = L.rays_in_out ? (unsigned long long *)(out + L.rays_offset) : L.rays_dst;
+            *dst = total; // rayweek1.cpp:809-813
+            __hip_atomic_store(L.frame_left + f, A.n_local_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads(); // s_part is reused by the next tile
+    return good;
+}
+
+// the life of a resolver workgroup (blockIdx.x < A.land_res); all R1_BLOCK threads
+__device__ __forceinline__ void land_resolver(const R1TraceArgs &A)
+{
+    __shared__ uint32_t s_pick;
+    __shared__ unsigned long long s_part[4];
+    const R1LandArgs &L = A.land;
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const uint32_t r = blockIdx.x, R = A.land_res;
+    const uint32_t tiles_all = A.n_local_tiles * L.n_frames;
+    const uint32_t owned = r < tiles_all ? (tiles_all - r + R - 1u) / R : 0u; // tiles r, r + R, ...
+    // the queue heads the launch before this one used (the other set): nobody touches them during this launch
+    if (r == 0u && (uint32_t)tid < L.clear_count)
+        L.clear_heads[32u * (uint32_t)tid] = 0u;
+    uint32_t cursor = 0;         // owned tiles [0, cursor) are done
+    uint32_t fails = 0;          // passes over a tile that found a record without the launch's tag, in a row
+    unsigned long long done = 0; // bit i: owned tile cursor + i is done (the tiles of a frame complete roughly, not exactly, in order)
+    while (cursor < owned)
+    {
+        if (tid < 64)
+        {
+            unsigned long long ready;
+            uint32_t polls = 0;
+            for (;;)
+            {
+                const uint32_t i = cursor + (uint32_t)lane;
+                const bool in = i < owned && !((done >> lane) & 1ull);
+                uint32_t c = 1u;
+                if (in)
+                    c = __hip_atomic_load(A.land_cnt + (i * R + r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ready = __ballot(in && c == 0u);
+                if (ready || ++polls == R1_LAND_MAX_WAIT)
+                    break;
+                __builtin_amdgcn_s_sleep(32); // ~1 us
+            }
+            if (lane == 0)
+                s_pick = ready ? cursor + (uint32_t)(__ffsll((long long)ready) - 1) : 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        const uint32_t oi = s_pick;
+        if (oi == 0xFFFFFFFFu || fails == R1_LAND_MAX_WAIT)
+        {
+            if (tid == 0 && L.error)
+                *L.error = 1u; // the host reports the launch as failed (r1_sync / r1_render)
+            return;
+        }
+        if (land_resolve_tile(A, oi * R + r, s_part)) // (ends with a barrier: s_pick may be written again)
+        {
+            done |= 1ull << (oi - cursor);
+            while (done & 1ull)
+                done >>= 1, ++cursor;
+            fails = 0;
+        }
+        else
+        {
+            ++fails;
+            __builtin_amdgcn_s_sleep(16); // a record of the tile was still on its way
+        }
+    }
+}
+
 } // namespace
 
 // ============================================================================================
@@ -1278,6 +1467,16 @@ template <int VARIANT, bool STATS, bool BIG, int MODE>
 __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MODE>::value)) r1_trace_kernel(const R1TraceArgs A)
 {
     constexpr bool LAT = MODE == 1, PIX = MODE == 2, BATCH = MODE == 3; // MODE 3 = MODE 0 whose queue spans the frames of a batch
+    // tiles resolved inside the kernel: the product kernels (not the diagnostic builds, PIXEL mode or the reference-form
+    // sweep); a launch through them has land_res >= 1 (r1_launch_trace checks)
+    constexpr bool LAND = R1_LAND && !STATS && !PIX && VARIANT != 1;
+    const uint32_t n_res = LAND ? A.land_res : 0u; // resolver workgroups at the front of the grid
+    if (LAND && blockIdx.x < n_res)
+    {
+        land_resolver(A);
+        return;
+    }
+    const uint32_t tb = blockIdx.x - n_res, n_tb = gridDim.x - n_res; // this tracing workgroup, of so many
     typedef typename IdxType<BIG>::type IDX;
     unsigned long long wstat[18];
     if (STATS)
@@ -1302,7 +1501,7 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
     __shared__ IDX s_pairs[VARIANT == 2 ? (R1_BLOCK / 64) * PairBits<IDX>::cap : 1];
     // R1_VARIANT_BVH: traversal stack [tree depth][thread], sized at launch (dynamic LDS)
     extern __shared__ uint32_t s_trav[];
-    const uint32_t gstride = gridDim.x * R1_BLOCK, gtid = blockIdx.x * R1_BLOCK + threadIdx.x;
+    const uint32_t gstride = n_tb * R1_BLOCK, gtid = tb * R1_BLOCK + threadIdx.x;
     __shared__ unsigned long long s_best[VARIANT == 2 ? R1_BLOCK : 1];
     __shared__ f4 s_tile[BIG && VARIANT == 2 ? 2 * R1_TILE_F4 : 1];
 
@@ -1371,12 +1570,12 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
     uint32_t q_next = 0, q_end = 0;
     const uint32_t q_total = A.total_samples;
     uint32_t q_remaining = q_total;
-    const uint32_t n_waves2 = 2u * gridDim.x * (R1_BLOCK / 64);
+    const uint32_t n_waves2 = 2u * n_tb * (R1_BLOCK / 64);
     bool exhausted = false;
     // sub-queue this wave pulls from (A.nq > 1), wave-uniform
     // (workgroups b .. b + 7 sit on the eight XCDs and share their sub-queues, so every sub-queue is served from
     // every XCD: the XCDs of one chip ran this kernel up to 20 % apart in speed, tools/wave_timeline.py)
-    const uint32_t home = LAT && A.nq > 1 ? __builtin_amdgcn_readfirstlane(((blockIdx.x >> 3) * (R1_BLOCK / 64) + (threadIdx.x >> 6)) % A.nq) : 0u;
+    const uint32_t home = LAT && A.nq > 1 ? __builtin_amdgcn_readfirstlane(((tb >> 3) * (R1_BLOCK / 64) + (threadIdx.x >> 6)) % A.nq) : 0u;
 
     for (;;)
     {
@@ -1535,6 +1734,7 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
             wstat[15] = __builtin_readcyclecounter();
         }
 
+        bool fin = false; // this lane's sample ended in this iteration
         if (ready)
         {
             V3 col;
@@ -1546,14 +1746,19 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
                     if (++px.s == (uint32_t)A.spp)
                         pixel_write(A, px);
                 }
+                else if (LAND)
+                    land_store(A.samples + p.k, col, p.rays | A.land_tag);
                 else
                     A.samples[p.k] = make_float4(col.x, col.y, col.z, __uint_as_float(p.rays));
-                lane_rays += p.rays;
-                alive = false;
+                if (!LAND)
+                    lane_rays += p.rays; // (LAND: the resolvers add up the records' counts)
+                alive = false, fin = true;
             }
             else if (VARIANT == 4)
                 trav_start(tv); // the scattered ray starts its walk at the root
         }
+        if (LAND)
+            land_count(A, fin, p.k, lane);
         if (STATS)
             wstat[7] += __builtin_readcyclecounter() - wstat[15];
     }
@@ -1601,390 +1806,13 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
     }
 
     // ray count: wave reduction, one atomic per wave (rayweek1.cpp:809-813)
-    for (int off = 32; off > 0; off >>= 1)
-        lane_rays += __shfl_down(lane_rays, off, 64);
-    if (lane == 0 && lane_rays)
-        atomicAdd(A.num_rays, lane_rays);
-}
-
-
-// ============================================================================================
-// Wavefront variant (R1_VARIANT_WAVEFRONT; SURVEY.md §8f-3 "the step either side of the
-// megakernel"): generate -> [intersect -> shade] x (max_bounces + 1) with the path state and
-// one queue of live path slots per color() level in HBM.  Same device functions as the
-// megakernel (start_sample, sweep_bvh, shade_level), so the samples are bit-identical; what
-// differs is where the state lives between steps.  Measured against the megakernel in
-// DESIGN.md §4.5.
-// ============================================================================================
-namespace
-{
-
-// all lanes of the wave call this together; lanes with `want` get consecutive queue slots
-__device__ __forceinline__ void wave_append(uint32_t *counter, uint32_t *queue, const bool want, const uint32_t value)
-{
-    const unsigned long long m = __ballot(want);
-    if (m == 0ull)
-        return;
-    const int lane = (int)(threadIdx.x & 63u);
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if (lane == leader)
-        base = atomicAdd(counter, (uint32_t)__popcll(m));
-    base = (uint32_t)__shfl((int)base, leader, 64);
-    if (want)
-        queue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
-}
-
-} // namespace
-
-// sample slot k -> primary ray (rayweek1.cpp:759-760) in path slot k; void slots are skipped
-__global__ void __launch_bounds__(R1_BLOCK) r1_wf_generate(const R1WaveArgs W)
-{
-    const uint32_t stride = gridDim.x * R1_BLOCK;
-    const uint32_t rounds = (W.n_paths + stride - 1) / stride; // every lane makes the same number of trips (wave_append)
-    for (uint32_t r = 0; r < rounds; ++r)
+    if (!LAND)
     {
-        const uint32_t k = r * stride + blockIdx.x * R1_BLOCK + threadIdx.x;
-        Path p;
-        bool valid = false;
-        if (k < W.n_paths)
-            valid = start_sample(W.t, p, k);
-        if (valid)
-            path_store(W.paths, W.n_paths, k, p);
-        wave_append(&W.counts[0], W.queue[0], valid, k);
+        for (int off = 32; off > 0; off >>= 1)
+            lane_rays += __shfl_down(lane_rays, off, 64);
+        if (lane == 0 && lane_rays)
+            atomicAdd(A.num_rays, lane_rays);
     }
 }
 
-// Hitable::hit for every path of the level's queue (rayweek1.cpp:519)
-__global__ void __launch_bounds__(R1_BLOCK) r1_wf_intersect(const R1WaveArgs W)
-{
-    extern __shared__ uint32_t s_trav[];
-    const uint32_t n = W.counts[W.level];
-    const uint32_t *q = W.queue[W.level & 1];
-    const uint32_t stride = gridDim.x * R1_BLOCK;
-    for (uint32_t i = blockIdx.x * R1_BLOCK + threadIdx.x; i < n; i += stride)
-    {
-        const uint32_t slot = q[i];
-        const float4 a = W.paths[slot], b = W.paths[(size_t)W.n_paths + slot];
-        float t_hit = FLT_MAX;
-        int hit = -1;
-        sweep_bvh<false>(W.t.scene, true, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), t_hit, hit, s_trav, (int)threadIdx.x, nullptr);
-        W.hits[slot] = make_float2(t_hit, __int_as_float(hit));
-    }
-}
-
-// the rest of color() for the level: scatter into the next level's queue, or finish the sample
-__global__ void __launch_bounds__(R1_BLOCK) r1_wf_shade(const R1WaveArgs W)
-{
-    const uint32_t n = W.counts[W.level];
-    const uint32_t *q = W.queue[W.level & 1];
-    uint32_t *qn = W.queue[(W.level + 1) & 1];
-    const uint32_t stride = gridDim.x * R1_BLOCK;
-    const uint32_t rounds = (n + stride - 1) / stride;
-    unsigned long long lane_rays = 0;
-    for (uint32_t r = 0; r < rounds; ++r)
-    {
-        const uint32_t i = r * stride + blockIdx.x * R1_BLOCK + threadIdx.x;
-        bool goes_on = false;
-        uint32_t slot = 0;
-        if (i < n)
-        {
-            slot = q[i];
-            Path p;
-            path_load(W.paths, W.n_paths, slot, p);
-            const float2 h = W.hits[slot];
-            V3 col;
-            if (shade_level<true>(W.t, p, __float_as_int(h.y), h.x, nullptr, W.n_paths, slot, (int)threadIdx.x, col))
-            {
-                W.t.samples[p.k] = make_float4(col.x, col.y, col.z, __uint_as_float(p.rays));
-                lane_rays += p.rays;
-            }
-            else
-            {
-                path_store(W.paths, W.n_paths, slot, p);
-                goes_on = true;
-            }
-        }
-        wave_append(&W.counts[W.level + 1], qn, goes_on, slot);
-    }
-    for (int off = 32; off > 0; off >>= 1)
-        lane_rays += __shfl_down(lane_rays, off, 64);
-    if ((threadIdx.x & 63u) == 0 && lane_rays)
-        atomicAdd(W.t.num_rays, lane_rays);
-}
-
-// ============================================================================================
-// Resolve: one thread per pixel of this shard; sums the spp samples in sample order and
-// quantises exactly as rayweek1.cpp:765-775.
-// ============================================================================================
-__global__ void __launch_bounds__(256) r1_resolve_kernel(const R1ResolveArgs A)
-{
-    if (blockIdx.x == 0 && blockIdx.y == 0 && A.rays_src)
-    {
-        static_assert(R1_COUNTER_BYTES == 256 * 16, "one 16-byte store per thread zeroes the counter block");
-        if (threadIdx.x == 0)
-            *A.rays_dst = *A.rays_src;
-        __syncthreads();
-        if (A.reset)
-            ((uint4 *)A.reset)[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
-    }
-    const uint32_t tiles_stride = gridDim.y;
-    const uint32_t tiles_all = A.n_local_tiles * (A.n_frames ? A.n_frames : 1u);
-    for (uint32_t lt_all = blockIdx.y; lt_all < tiles_all; lt_all += tiles_stride)
-    {
-        const uint32_t f = lt_all / A.n_local_tiles, lt = lt_all - f * A.n_local_tiles; // frame of the batch, its local tile
-        uint8_t *const out = A.out + (size_t)f * A.out_stride;
-        const uint32_t tile = (uint32_t)A.shard + lt * (uint32_t)A.num_shards;
-        const int x0 = (int)(tile % (uint32_t)A.tiles_x) * A.tile_w;
-        const int y0 = (int)(tile / (uint32_t)A.tiles_x) * A.tile_h;
-        const int tw = min(A.tile_w, A.width - x0);
-        const int th = min(A.tile_h, A.height - y0);
-        const uint32_t base = lt_all * A.full;
-        unsigned long long rays = 0;
-        for (uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x; pix < (uint32_t)(A.tile_w * A.tile_h); pix += gridDim.x * blockDim.x)
-        {
-            const int ly = (int)(pix / (uint32_t)A.tile_w);
-            const int lx = (int)(pix - (uint32_t)ly * (uint32_t)A.tile_w);
-            if (lx >= tw || ly >= th)
-                continue; // void slots of an edge tile
-            const uint32_t tile_px = (uint32_t)(A.tile_w * A.tile_h);
-            const float4 *s = A.samples + base + pix; // [tile][sample][pixel]
-            float cr = 0, cg = 0, cb = 0;
-            for (int i = 0; i < A.spp; ++i)
-            {
-                const float4 v = s[(size_t)i * tile_px];
-                cr += v.x, cg += v.y, cb += v.z; // col += color(...) rayweek1.cpp:762
-                rays += __float_as_uint(v.w);
-            }
-            cr *= A.inv_spp, cg *= A.inv_spp, cb *= A.inv_spp;
-            cr = ieee_sqrt(cr), cg = ieee_sqrt(cg), cb = ieee_sqrt(cb);
-            const uint8_t r = (uint8_t)(int)(cr * 255.99f);
-            const uint8_t g = (uint8_t)(int)(cg * 255.99f);
-            const uint8_t b = (uint8_t)(int)(cb * 255.99f);
-            size_t o;
-            if (A.block_layout)
-                o = ((size_t)lt * A.tile_h * A.tile_w + (size_t)ly * A.tile_w + lx) * 3;
-            else
-                o = ((size_t)(y0 + ly) * A.width + (x0 + lx)) * 3;
-            out[o + 0] = r;
-            out[o + 1] = g;
-            out[o + 2] = b;
-        }
-        if (A.frame_rays) // frame batches: the frame's ray count is the sum over its samples (rayweek1.cpp:809-813)
-        {
-            // no atomics: 15 000 waves adding to one word per frame cost more than the whole resolve (a returning or
-            // non-returning atomic on ONE line sustains ~88 M/s on this chip, tools/ubench_atomic.hip).  Every workgroup
-            // stores ONE partial sum per tile it touches; r1_batch_counts_kernel adds them up per frame.
-            __shared__ unsigned long long s_part[4];
-            for (int off = 32; off > 0; off >>= 1)
-                rays += __shfl_down(rays, off, 64);
-            if ((threadIdx.x & 63u) == 0)
-                s_part[threadIdx.x >> 6] = rays;
-            __syncthreads();
-            if (threadIdx.x == 0)
-                A.frame_rays[(size_t)lt_all * gridDim.x + blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-            __syncthreads();
-        }
-    }
-}
-
-// Frame batches: frame f's ray count = the sum of the partial sums the resolve launch left per (tile, workgroup column);
-// one workgroup per frame; the count goes next to the frame's pixels (out + f * out_stride + rays_offset).
-__global__ void __launch_bounds__(256)
-    r1_batch_counts_kernel(const unsigned long long *__restrict__ partial, uint32_t per_frame, uint8_t *__restrict__ out, size_t out_stride,
-                           size_t rays_offset)
-{
-    __shared__ unsigned long long s_part[4];
-    const unsigned long long *src = partial + (size_t)blockIdx.x * per_frame;
-    unsigned long long sum = 0;
-    for (uint32_t i = threadIdx.x; i < per_frame; i += blockDim.x)
-        sum += src[i];
-    for (int off = 32; off > 0; off >>= 1)
-        sum += __shfl_down(sum, off, 64);
-    if ((threadIdx.x & 63u) == 0)
-        s_part[threadIdx.x >> 6] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0)
-        *(unsigned long long *)(out + (size_t)blockIdx.x * out_stride + rays_offset) = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-}
-
-// Scatter gathered dense tile blocks (shard-major) into a row-major image.  Frame batches: blockIdx.y = frame; the
-// frame's blocks start frame_in bytes after `blocks` (gathered layout [shard][frame][record]) and its image frame_out
-// bytes after `rgb`.
-__global__ void __launch_bounds__(256)
-    r1_assemble_kernel(const uint8_t *__restrict__ blocks_all, uint8_t *__restrict__ rgb_all, int width, int height, int tile_w, int tile_h,
-                       int tiles_x, int num_shards, size_t shard_stride, size_t frame_in, size_t frame_out, size_t total_offset, long long total_out,
-                       int want_total)
-{
-    const uint8_t *__restrict__ blocks = blocks_all + (size_t)blockIdx.y * frame_in;
-    uint8_t *__restrict__ rgb = rgb_all + (size_t)blockIdx.y * frame_out;
-    // gathered RECORDS (block + uint64 count at the end of every record): the frame's ray count is the sum of the
-    // shards' counts (rayweek1.cpp:809-813), written next to the image so that one copy brings both to the host
-    if (want_total && blockIdx.x == 0 && threadIdx.x == 0)
-    {
-        unsigned long long sum = 0;
-        for (int sh = 0; sh < num_shards; ++sh)
-            sum += *(const unsigned long long *)(blocks + (size_t)sh * shard_stride + total_offset);
-        *(unsigned long long *)(rgb + total_out) = sum;
-    }
-    const size_t n = (size_t)width * height;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    {
-        const int y = (int)(i / (size_t)width), x = (int)(i - (size_t)y * width);
-        const int tile = (y / tile_h) * tiles_x + (x / tile_w);
-        const int shard = tile % num_shards, lt = tile / num_shards;
-        const size_t src = (size_t)shard * shard_stride + (((size_t)lt * tile_h + (size_t)(y % tile_h)) * tile_w + (x % tile_w)) * 3;
-        rgb[3 * i + 0] = blocks[src + 0];
-        rgb[3 * i + 1] = blocks[src + 1];
-        rgb[3 * i + 2] = blocks[src + 2];
-    }
-}
-
-// ---- launchers (called from r1_capi.cpp) -----------------------------------------------------
-
-// The kernel mode that is built for (variant, big) given what the caller would like (0 samples + one guided queue,
-// 1 latency, 2 pixel): the reference-form sweep only exists in mode 0, the diagnostic builds follow the latency
-// mode, big scenes have no latency mode.
-extern "C" int r1_trace_mode(int variant, int big, int wanted)
-{
-    if (variant == 1)
-        return 0;
-    if (variant == 3 || variant == 5)
-        return big ? 0 : 1;
-    if (wanted == 1)
-        return big ? 0 : 1;
-    return wanted == 2 ? 2 : 0;
-}
-
-extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int big_in, int mode, int blocks, hipStream_t stream)
-{
-    // dynamic LDS of the tree kernels: the traversal stack, one entry per inner node on a path, and (small scenes) the node table
-    const bool big = big_in != 0; // 32-bit hit indices, attenuation stack in the global workspace
-    const size_t trav = ((variant == 4 || variant == 5) ? (size_t)args->bvh_depth * R1_BLOCK * (big ? sizeof(uint32_t) : sizeof(uint16_t)) + (size_t)args->bvh_lds_f4 * 16 : 0);
-#define R1_GO(V, S, B, M) hipLaunchKernelGGL((r1_trace_kernel<V, S, B, M>), dim3(blocks), dim3(R1_BLOCK), (V) == 4 ? trav : 0, stream, *args)
-    if (mode != r1_trace_mode(variant, big_in, mode))
-        return hipErrorInvalidValue; // the caller sizes its arguments by the mode: it must be the one that is built
-    const bool batch = args->batch != nullptr; // frame batches: the MODE 3 build of the throughput kernels (variants 2 and 4 only)
-    if (batch && (mode != 0 || (variant != 2 && variant != 4)))
-        return hipErrorInvalidValue;
-    if (variant == 5 && big)
-        R1_GO(4, true, true, 0);
-    else if (variant == 5)
-        R1_GO(4, true, false, 1); // the diagnostic builds follow the latency-mode kernels (they are only run synchronously)
-    else if (variant == 4 && big)
-    {
-        if (mode == 2)
-            R1_GO(4, false, true, 2);
-        else if (batch)
-            R1_GO(4, false, true, 3);
-        else
-            R1_GO(4, false, true, 0);
-    }
-    else if (variant == 4)
-    {
-        if (mode == 2)
-            R1_GO(4, false, false, 2);
-        else if (mode == 1)
-            R1_GO(4, false, false, 1);
-        else if (batch)
-            R1_GO(4, false, false, 3);
-        else
-            R1_GO(4, false, false, 0);
-    }
-    else if (variant == 1 && big)
-        R1_GO(1, false, true, 0);
-    else if (variant == 1)
-        R1_GO(1, false, false, 0);
-    else if (variant == 3 && !big)
-        R1_GO(2, true, false, 1);
-    else if (big)
-    {
-        if (mode == 2)
-            R1_GO(2, false, true, 2);
-        else if (batch)
-            R1_GO(2, false, true, 3);
-        else
-            R1_GO(2, false, true, 0);
-    }
-    else if (mode == 2)
-        R1_GO(2, false, false, 2);
-    else if (mode == 1)
-        R1_GO(2, false, false, 1);
-    else if (batch)
-        R1_GO(2, false, false, 3);
-    else
-        R1_GO(2, false, false, 0);
-#undef R1_GO
-    return hipGetLastError();
-}
-
-// generate + (max_bounces + 1) x (intersect, shade); every launch reads its queue length on the device
-extern "C" hipError_t r1_launch_wavefront(R1WaveArgs *w, int blocks, hipStream_t stream)
-{
-    const size_t trav = (size_t)w->t.bvh_depth * R1_BLOCK * sizeof(uint32_t);
-    hipLaunchKernelGGL(r1_wf_generate, dim3(blocks), dim3(R1_BLOCK), 0, stream, *w);
-    for (int level = 0; level <= w->t.max_bounces; ++level)
-    {
-        w->level = level;
-        hipLaunchKernelGGL(r1_wf_intersect, dim3(blocks), dim3(R1_BLOCK), trav, stream, *w);
-        hipLaunchKernelGGL(r1_wf_shade, dim3(blocks), dim3(R1_BLOCK), 0, stream, *w);
-    }
-    return hipGetLastError();
-}
-
-// max_rows: at most this many rows of workgroups (one row walks tiles row, row + rows, ...); 0 = one row per tile.  Frames in flight use
-// FEW, long-lived workgroups: a resolve launch shares the chip with persistent trace workgroups and gets a slot only when one of them
-// exits, so what it costs is the number of slot grants it needs, not its 26 us of work (profiles/r03/burst_timeline_20_frames.txt).
-extern "C" hipError_t r1_launch_resolve(const R1ResolveArgs *args, int max_rows, hipStream_t stream)
-{
-    const int tile_pix = args->tile_w * args->tile_h;
-    const int bx = (tile_pix + 255) / 256;
-    const uint32_t tiles_all = args->n_local_tiles * (args->n_frames ? args->n_frames : 1u);
-    int by = (int)(tiles_all < 65535u ? tiles_all : 65535u);
-    if (max_rows > 0 && by > max_rows)
-        by = max_rows;
-    hipLaunchKernelGGL(r1_resolve_kernel, dim3(bx, by), dim3(256), 0, stream, *args);
-    if (args->frame_rays) // frame batches: per-frame ray counts from the launch's partial sums ([tile of the batch][bx])
-        hipLaunchKernelGGL(r1_batch_counts_kernel, dim3(args->n_frames), dim3(256), 0, stream, args->frame_rays, args->n_local_tiles * (uint32_t)bx,
-                           args->out, args->out_stride, args->rays_offset);
-    return hipGetLastError();
-}
-
-// blocks: gathered tile blocks or records; per frame f (0 .. n_frames - 1): shard sh's block at blocks + f * frame_in + sh * shard_stride,
-// image at rgb + f * frame_out.  want_total: the shards' uint64 counts at (block start + total_offset) are summed into the
-// uint64 at (the frame's image + total_out).
-extern "C" hipError_t r1_launch_assemble(const void *blocks, void *rgb, int width, int height, int tile_w, int tile_h, int tiles_x, int num_shards,
-                                         size_t shard_stride, int n_frames, size_t frame_in, size_t frame_out, size_t total_offset, long long total_out,
-                                         int want_total, hipStream_t stream)
-{
-    const size_t n = (size_t)width * height;
-    int grid = (int)((n + 255) / 256);
-    if (grid > 8192)
-        grid = 8192;
-    hipLaunchKernelGGL(r1_assemble_kernel, dim3(grid, n_frames > 0 ? n_frames : 1), dim3(256), 0, stream, (const uint8_t *)blocks, (uint8_t *)rgb, width,
-                       height, tile_w, tile_h, tiles_x, num_shards, shard_stride, frame_in, frame_out, total_offset, total_out, want_total);
-    return hipGetLastError();
-}
-
-extern "C" hipError_t r1_trace_occupancy(int variant, int big, int mode, size_t dyn_lds, int *blocks_per_cu)
-{
-#define R1_OCC(V, S, B, M) hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, r1_trace_kernel<V, S, B, M>, R1_BLOCK, (V) == 4 ? dyn_lds : 0)
-    if (variant == 5 && big)
-        return R1_OCC(4, true, true, 0);
-    if (variant == 5)
-        return R1_OCC(4, true, false, 1);
-    if (variant == 4 && big)
-        return mode == 2 ? R1_OCC(4, false, true, 2) : R1_OCC(4, false, true, 0);
-    if (variant == 4)
-        return mode == 2 ? R1_OCC(4, false, false, 2) : (mode == 1 ? R1_OCC(4, false, false, 1) : R1_OCC(4, false, false, 0));
-    if (variant == 1 && big)
-        return R1_OCC(1, false, true, 0);
-    if (variant == 1)
-        return R1_OCC(1, false, false, 0);
-    if (variant == 3 && !big)
-        return R1_OCC(2, true, false, 1);
-    if (big)
-        return mode == 2 ? R1_OCC(2, false, true, 2) : R1_OCC(2, false, true, 0);
-    return mode == 2 ? R1_OCC(2, false, false, 2) : (mode == 1 ? R1_OCC(2, false, false, 1) : R1_OCC(2, false, false, 0));
-#undef R1_OCC
-}
+#endif // R1_TRACE_HPP

@@ -1,0 +1,5 @@
+// r1_trace_sweep_big.hip — the trace kernel's instantiations for one family (r1_trace_tu.inc says which); kernel and device functions: r1_trace.hpp
+#define R1_TU_NAME sweep_big
+#define R1_TU_BIG true
+#define R1_TU_TREE 0
+#include "r1_trace_tu.inc"

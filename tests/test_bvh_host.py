@@ -2,7 +2,7 @@
 
 Structure: every hittable sphere sits in exactly one leaf slot, child boxes contain their
 spheres, depth fits the kernel's traversal stack.  Conservativeness: a numpy re-statement of the
-kernel's traversal rule (inflated slab test, r1_kernels.hip::bvh_box) must present every sphere
+kernel's traversal rule (inflated slab test, r1_trace.hpp::bvh_box) must present every sphere
 whose fp32 reference test can offer a hit (clear sign bit of the discriminant and a root
 beyond t_min, rayweek1.cpp:192-204, :294-313) — checked against
 brute force over all spheres for random and adversarial rays."""
@@ -113,7 +113,7 @@ def ref_flagged(cx, cy, cz, rsq, o, d):
 
 
 def traverse(nodes, centre, o, d, jitter=None, pad_local=0):
-    """The kernel's visit rule (r1_kernels.hip::bvh_box, fp32 step by step) without distance pruning: leaf slots the ray is shown."""
+    """The kernel's visit rule (r1_trace.hpp::bvh_box, fp32 step by step) without distance pruning: leaf slots the ray is shown."""
     o = o.astype(F)
 
     def fma(a, b, c):  # exactly rounded fp32 fma (the product of two fp32 is exact in fp64; inf/NaN propagate alike)

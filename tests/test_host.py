@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/rays1.h but not exported"
     assert declared == {s[0] for s in binding.SYMBOLS}
-    assert L.r1_abi_version() == 3
+    assert L.r1_abi_version() == 4
 
 
 def test_struct_layouts_match_header():
@@ -127,7 +127,7 @@ def test_product_does_not_touch_the_oracle():
     seen = 0
     for dp, _, fns in os.walk(pkg):
         for fn in fns:
-            if fn.endswith((".py", ".cpp", ".hip", ".h")) or fn == "Makefile":
+            if fn.endswith((".py", ".cpp", ".hip", ".h", ".hpp", ".inc")) or fn == "Makefile":
                 seen += 1
                 assert not bad.search(open(os.path.join(dp, fn)).read()), fn
     assert seen >= 7
