@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(256) r1_land_arm_kernel(uint32_t *tile_cnt, un
     const uint32_t tile = (uint32_t)shard + lt * (uint32_t)num_shards;
     const int x0 = (int)(tile % (uint32_t)tiles_x) * tile_w, y0 = (int)(tile / (uint32_t)tiles_x) * tile_h;
     const int tw = min(tile_w, width - x0), th = min(tile_h, height - y0);
-    tile_cnt[i] = (uint32_t)(tw * th * spp);
+    tile_cnt[(size_t)i * R1_LAND_CNT_STRIDE] = (uint32_t)(tw * th * spp);
 }
 
 // six words into device memory, the values travelling in the kernel arguments (copied when the launch is enqueued: no host buffer

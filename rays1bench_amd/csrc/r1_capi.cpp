@@ -682,7 +682,7 @@ static int ensure_counters(r1_context *c, const r1_params *p, int n_frames)
     if (rc)
         return rc;
     const size_t F = (size_t)(n_frames > 0 ? n_frames : 1);
-    const size_t need = land_frames_off() + F * 16 + F * (size_t)(c->n_local_tiles ? c->n_local_tiles : 1) * 4;
+    const size_t need = land_frames_off() + ((F * 16 + 127) & ~(size_t)127) + F * (size_t)(c->n_local_tiles ? c->n_local_tiles : 1) * 4 * R1_LAND_CNT_STRIDE;
     if (c->counters.p && need <= c->counters.cap)
         return R1_OK;
     R1_HIP(hipStreamSynchronize(c->stream)); // (a frame in flight on another stream is the caller's to order: one frame per context at a time)
@@ -999,7 +999,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
         a.land_res = (uint32_t)n_res;
         unsigned long long *frame_rays = (unsigned long long *)((char *)c->counters.p + land_frames_off());
         uint32_t *frame_left = (uint32_t *)(frame_rays + n_frames);
-        a.land_cnt = frame_left + ((n_frames + 1) & ~1);
+        a.land_cnt = (uint32_t *)((char *)frame_rays + (((size_t)n_frames * 16 + 127) & ~(size_t)127)); // (every countdown on a 128-byte line of its own)
         if (!c->land_armed || c->land_frames != n_frames || !same_tiling(c->land_key, *p))
         {
             R1_HIP(r1_launch_land_arm(a.land_cnt, frame_rays, frame_left, (uint32_t)n_frames, c->n_local_tiles, p->width, p->height, p->spp, p->tile_w, p->tile_h,

@@ -59,7 +59,10 @@
 #ifndef R1_LAND_RES_SYNC
 #define R1_LAND_RES_SYNC 32    // ... of a synchronous frame, whose grid fills the chip (taken from the tracing workgroups)
 #endif
-#define R1_LAND_MAX_WAIT (1u << 26) // resolver: polls (~1 us each) without any of its tiles completing, or failed passes over one tile, before it
+#define R1_LAND_CNT_STRIDE 32u  // words between two tiles' countdowns: every countdown on its own 128-byte line (an atomic on ONE line sustains ~88 M/s on this chip,
+                               // tools/ubench_atomic.hip; the ~40 tiles a synchronous frame's waves work on at a time shared two lines at first: 3.8 ms per frame instead of 1.1)
+#define R1_LAND_WINDOW 16u     // tiles of its own a resolver polls at a time (they complete roughly in order)
+#define R1_LAND_MAX_WAIT (1u << 25) // resolver: polls (~1 us each) without any of its tiles completing, or failed passes over one tile, before it
                                     // gives up and flags the launch (a miscount would otherwise hang the device instead of failing the call)
 #define R1_COUNTER_TAIL 4096   // behind the R1_COUNTER_BYTES block: +0 published ray count, +64 batch-argument slots (8 x 32 B), +1024 the second
                                // set of queue heads (frames alternate between the sets; the resolvers of a launch zero the set the
@@ -199,7 +202,7 @@ struct R1TraceArgs
     // R1_LAND (tiles resolved inside the kernel): land_res > 0 turns it on for this launch
     uint32_t land_res;            // workgroups 0 .. land_res - 1 are resolvers, the rest trace
     uint32_t land_tag;            // launch generation << 8, or-ed into every sample record's ray-count word: a record is the launch's own iff its tag matches
-    uint32_t *land_cnt;           // [n_frames * n_local_tiles] samples each tile still lacks; the tracing waves subtract, the tile's resolver re-arms
+    uint32_t *land_cnt;           // [n_frames * n_local_tiles] x R1_LAND_CNT_STRIDE words: samples each tile still lacks; the tracing waves subtract, the tile's resolver re-arms
     R1LandArgs land;
     uint32_t coop_lanes;          // small scenes: once the queue is empty, a wave with <= coop_lanes live paths tests each of them
                                   // against ALL spheres, 64 at a time across the wave (cooperative_sweep), instead of walking the tree

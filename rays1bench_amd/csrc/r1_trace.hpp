@@ -1269,10 +1269,17 @@ __device__ __forceinline__ bool shade_level(const R1TraceArgs &A, Path &p, const
 typedef float land_f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t land_u4 __attribute__((ext_vector_type(4)));
 
+#ifndef R1_LAND_EXP
+#define R1_LAND_EXP 0 // measurements only (make tuning EXTRA=-DR1_LAND_EXP=n; frames are NOT valid): 1 resolvers return at once, 2 and no countdown atomics, 3 and plain stores
+#endif
 __device__ __forceinline__ void land_store(float4 *dst, const V3 col, const uint32_t w)
 {
     const land_f4 v = {col.x, col.y, col.z, __uint_as_float(w)};
+#if R1_LAND_EXP >= 3
+    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
+#else
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+#endif
 }
 
 // the lanes with `fin` have just stored the record of sample slot k: count them into their tiles' countdowns (usually one tile per wave
@@ -1280,7 +1287,7 @@ __device__ __forceinline__ void land_store(float4 *dst, const V3 col, const uint
 __device__ __forceinline__ void land_count(const R1TraceArgs &A, const bool fin, const uint32_t k, const int lane)
 {
     unsigned long long rest = __ballot(fin);
-    if (rest == 0ull)
+    if (rest == 0ull || R1_LAND_EXP >= 2)
         return;
     const uint32_t j = fastdiv(k, A.div_full); // tile of the launch: k = (j spp + s) tile_px + pix
     do
@@ -1289,15 +1296,26 @@ __device__ __forceinline__ void land_count(const R1TraceArgs &A, const bool fin,
         const uint32_t j0 = (uint32_t)__builtin_amdgcn_readlane((int)j, l);
         const unsigned long long same = __ballot(fin && j == j0);
         if (lane == l)
-            (void)__hip_atomic_fetch_sub(A.land_cnt + j0, (uint32_t)__popcll(same), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_sub(A.land_cnt + j0 * R1_LAND_CNT_STRIDE, (uint32_t)__popcll(same), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         rest &= ~same;
     } while (rest);
 }
 
 // One tile of the launch (t = frame * n_local_tiles + local tile) by the whole workgroup: false if a record did not carry the launch's
-// tag (nothing is published then; pixels written from such a pass are overwritten by the pass that succeeds — the host sees the
-// buffer only after the kernel).  Same arithmetic and order as r1_resolve_kernel = rayweek1.cpp:762-775.
-__device__ __forceinline__ bool land_resolve_tile(const R1TraceArgs &A, const uint32_t t, unsigned long long *s_part /* [4] */)
+// tag (nothing is accounted then; pixels written from such a pass are overwritten by the pass that succeeds — the host sees the
+// buffer only after the kernel).  Same arithmetic and order as r1_resolve_kernel = rayweek1.cpp:762-775.  A thread keeps up to
+// R1_LAND_LOADS records of ONE pixel in flight (a resolver is bound by the latency of its loads, which go to memory: sc1).
+#define R1_LAND_LOADS 10
+#define R1_LAND_FRAMES_LDS 32 // frames of a batch whose counts a resolver accumulates in LDS (larger batches: atomics per tile)
+struct LandShared
+{
+    unsigned long long ready;                          // tiles of the resolver's window the last poll found complete (0: gave up)
+    unsigned long long part[4];                        // per-wave partial ray counts of the tile in hand
+    unsigned long long frame_rays[R1_LAND_FRAMES_LDS]; // this resolver's share of each frame's ray count ...
+    uint32_t frame_tiles[R1_LAND_FRAMES_LDS];          // ... and the tiles it stands for
+};
+
+__device__ __forceinline__ bool land_resolve_tile(const R1TraceArgs &A, const uint32_t t, LandShared &sh)
 {
     const R1LandArgs &L = A.land;
     const int tid = (int)threadIdx.x;
@@ -1311,6 +1329,7 @@ __device__ __forceinline__ bool land_resolve_tile(const R1TraceArgs &A, const ui
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(A.samples + (size_t)t * A.full), 0, (int)(A.full * 16u), 0x00020000);
     constexpr int SC1 = 16;
     uint8_t *const out = L.out + (size_t)f * L.out_stride;
+    const uint32_t spp = (uint32_t)A.spp;
     uint32_t bad = 0;
     unsigned long long rays = 0;
     for (uint32_t pix = (uint32_t)tid; pix < tile_px; pix += R1_BLOCK)
@@ -1319,27 +1338,22 @@ __device__ __forceinline__ bool land_resolve_tile(const R1TraceArgs &A, const ui
         if (lx >= tw || ly >= th)
             continue; // void slots of an edge tile
         float cr = 0, cg = 0, cb = 0;
-        int s = 0;
-        for (; s + 8 <= A.spp; s += 8)
+        for (uint32_t s0 = 0; s0 < spp; s0 += R1_LAND_LOADS)
         {
-            land_u4 v[8];
+            const uint32_t n = min((uint32_t)R1_LAND_LOADS, spp - s0); // (wave-uniform)
+            land_u4 v[R1_LAND_LOADS];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((((uint32_t)(s + u)) * tile_px + pix) * 16u), 0, SC1);
+            for (uint32_t u = 0; u < R1_LAND_LOADS; ++u)
+                if (u < n)
+                    v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((s0 + u) * tile_px + pix) * 16u), 0, SC1);
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-            {
-                cr += __uint_as_float(v[u].x), cg += __uint_as_float(v[u].y), cb += __uint_as_float(v[u].z); // col += color(...) rayweek1.cpp:762
-                bad |= (v[u].w & ~255u) ^ A.land_tag;
-                rays += v[u].w & 255u;
-            }
-        }
-        for (; s < A.spp; ++s)
-        {
-            const land_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((uint32_t)s * tile_px + pix) * 16u), 0, SC1);
-            cr += __uint_as_float(v.x), cg += __uint_as_float(v.y), cb += __uint_as_float(v.z);
-            bad |= (v.w & ~255u) ^ A.land_tag;
-            rays += v.w & 255u;
+            for (uint32_t u = 0; u < R1_LAND_LOADS; ++u)
+                if (u < n)
+                {
+                    cr += __uint_as_float(v[u].x), cg += __uint_as_float(v[u].y), cb += __uint_as_float(v[u].z); // col += color(...) rayweek1.cpp:762
+                    bad |= (v[u].w & ~255u) ^ A.land_tag;
+                    rays += v[u].w & 255u;
+                }
         }
         cr *= L.inv_spp, cg *= L.inv_spp, cb *= L.inv_spp;
         cr = ieee_sqrt(cr), cg = ieee_sqrt(cg), cb = ieee_sqrt(cb);
@@ -1351,33 +1365,54 @@ __device__ __forceinline__ bool land_resolve_tile(const R1TraceArgs &A, const ui
     for (int off = 32; off > 0; off >>= 1)
         rays += __shfl_down(rays, off, 64);
     if ((tid & 63) == 0)
-        s_part[tid >> 6] = rays;
-    const bool good = __syncthreads_or(bad != 0u) == 0; // (also the barrier between s_part's writes and its read)
+        sh.part[tid >> 6] = rays;
+    const bool good = __syncthreads_or(bad != 0u) == 0; // (also the barrier between part's writes and its read)
     if (good && tid == 0)
     {
-        // the tile's rays, then one tile less to go: the second atomic is issued only when the first has been performed
-        const unsigned long long before = __hip_atomic_fetch_add(L.frame_rays + f, s_part[0] + s_part[1] + s_part[2] + s_part[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("" ::"v"(before));
-        __hip_atomic_store(A.land_cnt + t, (uint32_t)(tw * th * A.spp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // re-armed for the next launch
-        const uint32_t left = __hip_atomic_fetch_sub(L.frame_left + f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (left == 1u)
+        const unsigned long long tile_rays = sh.part[0] + sh.part[1] + sh.part[2] + sh.part[3];
+        __hip_atomic_store(A.land_cnt + t * R1_LAND_CNT_STRIDE, (uint32_t)(tw * th) * spp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // re-armed for the next launch
+        if (L.n_frames <= R1_LAND_FRAMES_LDS)
+            sh.frame_rays[f] += tile_rays, sh.frame_tiles[f] += 1u; // (published when the resolver is through with its tiles: land_publish)
+        else
         {
-            // the frame's last tile: every other tile's rays have been added (their resolvers saw their add performed before they counted down)
-            const unsigned long long total = __hip_atomic_exchange(L.frame_rays + f, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned long long *dst = L.rays_in_out ? (unsigned long long *)(out + L.rays_offset) : L.rays_dst;
-            *dst = total; // rayweek1.cpp:809-813
-            __hip_atomic_store(L.frame_left + f, A.n_local_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the tile's rays, then one tile less to go: the second atomic is issued only when the first has been performed
+            const unsigned long long before = __hip_atomic_fetch_add(L.frame_rays + f, tile_rays, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("" ::"v"(before));
+            const uint32_t left = __hip_atomic_fetch_sub(L.frame_left + f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (left == 1u)
+            {
+                const unsigned long long total = __hip_atomic_exchange(L.frame_rays + f, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *(L.rays_in_out ? (unsigned long long *)(out + L.rays_offset) : L.rays_dst) = total; // rayweek1.cpp:809-813
+                __hip_atomic_store(L.frame_left + f, A.n_local_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
-    __syncthreads(); // s_part is reused by the next tile
+    __syncthreads(); // part is reused by the next tile
     return good;
 }
 
-// the life of a resolver workgroup (blockIdx.x < A.land_res); all R1_BLOCK threads
+// A resolver's share of frame f's count joins the frame's: its rays, then its tiles — the second atomic is issued only when the first
+// has been performed, so whoever takes the frame's last tiles off finds every share added — and that one publishes the count
+// (rayweek1.cpp:809-813) and leaves the accumulators as the next launch expects them.
+__device__ __forceinline__ void land_publish(const R1TraceArgs &A, const uint32_t f, const unsigned long long rays, const uint32_t tiles)
+{
+    const R1LandArgs &L = A.land;
+    const unsigned long long before = __hip_atomic_fetch_add(L.frame_rays + f, rays, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(before));
+    const uint32_t left = __hip_atomic_fetch_sub(L.frame_left + f, tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (left == tiles)
+    {
+        const unsigned long long total = __hip_atomic_exchange(L.frame_rays + f, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *(L.rays_in_out ? (unsigned long long *)(L.out + (size_t)f * L.out_stride + L.rays_offset) : L.rays_dst) = total;
+        __hip_atomic_store(L.frame_left + f, A.n_local_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// the life of a resolver workgroup (blockIdx.x < A.land_res); all R1_BLOCK threads.  (Inlined: as a called function it turns the
+// kernel's scalar spills into scratch traffic and its arguments into flat loads — 660 bytes of scratch per lane.)
 __device__ __forceinline__ void land_resolver(const R1TraceArgs &A)
 {
-    __shared__ uint32_t s_pick;
-    __shared__ unsigned long long s_part[4];
+    __shared__ LandShared sh;
     const R1LandArgs &L = A.land;
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const uint32_t r = blockIdx.x, R = A.land_res;
@@ -1386,9 +1421,14 @@ __device__ __forceinline__ void land_resolver(const R1TraceArgs &A)
     // the queue heads the launch before this one used (the other set): nobody touches them during this launch
     if (r == 0u && (uint32_t)tid < L.clear_count)
         L.clear_heads[32u * (uint32_t)tid] = 0u;
+    if (R1_LAND_EXP)
+        return;
+    if (tid < R1_LAND_FRAMES_LDS)
+        sh.frame_rays[tid] = 0ull, sh.frame_tiles[tid] = 0u;
     uint32_t cursor = 0;         // owned tiles [0, cursor) are done
-    uint32_t fails = 0;          // passes over a tile that found a record without the launch's tag, in a row
     unsigned long long done = 0; // bit i: owned tile cursor + i is done (the tiles of a frame complete roughly, not exactly, in order)
+    uint32_t fails = 0;          // passes in a row that found a record without the launch's tag
+    bool gave_up = false;
     while (cursor < owned)
     {
         if (tid < 64)
@@ -1398,39 +1438,45 @@ __device__ __forceinline__ void land_resolver(const R1TraceArgs &A)
             for (;;)
             {
                 const uint32_t i = cursor + (uint32_t)lane;
-                const bool in = i < owned && !((done >> lane) & 1ull);
+                const bool in = (uint32_t)lane < R1_LAND_WINDOW && i < owned && !((done >> lane) & 1ull);
                 uint32_t c = 1u;
                 if (in)
-                    c = __hip_atomic_load(A.land_cnt + (i * R + r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    c = __hip_atomic_load(A.land_cnt + (i * R + r) * R1_LAND_CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ready = __ballot(in && c == 0u);
                 if (ready || ++polls == R1_LAND_MAX_WAIT)
                     break;
-                __builtin_amdgcn_s_sleep(32); // ~1 us
+                __builtin_amdgcn_s_sleep(64); // ~2 us
             }
             if (lane == 0)
-                s_pick = ready ? cursor + (uint32_t)(__ffsll((long long)ready) - 1) : 0xFFFFFFFFu;
+                sh.ready = ready;
         }
         __syncthreads();
-        const uint32_t oi = s_pick;
-        if (oi == 0xFFFFFFFFu || fails == R1_LAND_MAX_WAIT)
+        unsigned long long todo = sh.ready;
+        if (todo == 0ull || fails >= R1_LAND_MAX_WAIT)
         {
-            if (tid == 0 && L.error)
-                *L.error = 1u; // the host reports the launch as failed (r1_sync / r1_render)
-            return;
+            gave_up = true;
+            break;
         }
-        if (land_resolve_tile(A, oi * R + r, s_part)) // (ends with a barrier: s_pick may be written again)
+        while (todo) // every tile the poll found complete (a resolve ends with a barrier: sh.ready is not rewritten before all have read it)
         {
-            done |= 1ull << (oi - cursor);
-            while (done & 1ull)
-                done >>= 1, ++cursor;
-            fails = 0;
+            const int b = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            if (land_resolve_tile(A, (cursor + (uint32_t)b) * R + r, sh))
+                done |= 1ull << b, fails = 0;
+            else
+                ++fails; // a record of the tile was still on its way: the next poll offers the tile again
         }
-        else
-        {
-            ++fails;
-            __builtin_amdgcn_s_sleep(16); // a record of the tile was still on its way
-        }
+        while (done & 1ull)
+            done >>= 1, ++cursor;
     }
+    if (gave_up)
+    {
+        if (tid == 0 && L.error)
+            *L.error = 1u; // the host reports the launch as failed (r1_sync / r1_render) and re-arms the countdowns
+        return;
+    }
+    if (L.n_frames <= R1_LAND_FRAMES_LDS && (uint32_t)tid < L.n_frames && sh.frame_tiles[tid])
+        land_publish(A, (uint32_t)tid, sh.frame_rays[tid], sh.frame_tiles[tid]);
 }
 
 } // namespace
