@@ -306,7 +306,7 @@ typedef struct r1_launch_info
     int32_t bvh_nodes;      /* inner nodes of the spatial index                   */
     int32_t bvh_leaves;
     int32_t bvh_depth;      /* inner nodes on the longest root-to-leaf path       */
-    int32_t resolver_blocks; /* workgroups of the launch that resolve finished tiles instead of tracing (in front of `blocks`; 0: a resolve launch follows) */
+    int32_t tiles_in_kernel; /* 1: the trace launch summed its tiles itself (frames in flight); 0: a resolve launch followed */
 } r1_launch_info;
 int r1_last_launch_info(r1_context *ctx, r1_launch_info *out);
 

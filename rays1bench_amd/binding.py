@@ -4,6 +4,7 @@ interface for the hot path (src/step13/rayweek1.cpp:552-719 scene builders, :845
 src/common/common.h:36-122 RESULT / log_results / tga_write_rgb24)."""
 import ctypes as C
 import os
+import sys
 import subprocess
 import time
 
@@ -17,6 +18,20 @@ LIBDIR = os.path.join(HERE, "lib")
 R1_OK, R1_EINVAL, R1_ENODEVICE, R1_EHIP, R1_ENOMEM, R1_ELIMIT = 0, -1, -2, -3, -4, -5
 SCENE_SMALL, SCENE_MEDIUM, SCENE_LARGE, SCENE_GRID = 0, 1, 2, 3
 VARIANT_DEFAULT, VARIANT_REFERENCE, VARIANT_PREFILTER, VARIANT_STATS, VARIANT_BVH, VARIANT_BVH_STATS, VARIANT_WAVEFRONT = 0, 1, 2, 3, 4, 5, 6
+
+
+
+def _stream_arg(stream_ptr):
+    """hipStream_t argument of the device-pointer entry points.  0 / None means the CONTEXT'S OWN stream (a non-blocking stream: the
+    library never touches the null stream), which is not ordered with torch's default stream — where a caller who passes
+    torch.cuda.current_stream().cuda_stream (= 0 for the default stream) has just filled the buffers it hands over.  So for that case
+    the pending work of torch's current stream is waited for here (tests and smoke only: bench.py passes streams of its own)."""
+    if stream_ptr:
+        return C.c_void_p(stream_ptr)
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
+        torch.cuda.current_stream().synchronize()
+    return None
 
 
 class R1Error(RuntimeError):
@@ -51,7 +66,7 @@ class LaunchInfo(C.Structure):
     _fields_ = [("compute_units", C.c_int32), ("blocks", C.c_int32), ("threads_per_block", C.c_int32),
                 ("spheres_active", C.c_int32), ("spheres_padded", C.c_int32), ("groups", C.c_int32), ("samples", C.c_uint64),
                 ("kernel", C.c_int32), ("bvh_nodes", C.c_int32), ("bvh_leaves", C.c_int32), ("bvh_depth", C.c_int32),
-                ("resolver_blocks", C.c_int32)]
+                ("tiles_in_kernel", C.c_int32)]
 
 
 class BvhInfo(C.Structure):
@@ -258,41 +273,41 @@ class Renderer:
         """r1_render_async: enqueue one frame (throughput kernels) whose pixels + ray count land in `host_frame`
         (a HostFrame) once the stream is idle."""
         _check(lib().r1_render_async(self._c, C.byref(params), C.cast(host_frame.ptr, _u8p),
-                                     C.cast(host_frame.ptr + host_frame.rays_offset, _u64p), C.c_void_p(stream_ptr) if stream_ptr else None))
+                                     C.cast(host_frame.ptr + host_frame.rays_offset, _u64p), _stream_arg(stream_ptr)))
 
     def render_batch_async(self, params, n_frames, host_frames, seed_stride=0, stream_ptr=None):
         """r1_render_batch_async: n_frames frames in one launch; their records land in `host_frames` (a HostFrames, or None
         to leave them on the device) once the stream is idle."""
         _check(lib().r1_render_batch_async(self._c, C.byref(params), n_frames, seed_stride, C.c_void_p(host_frames.ptr) if host_frames else None,
-                                           C.c_void_p(stream_ptr) if stream_ptr else None))
+                                           _stream_arg(stream_ptr)))
 
     def render_shard_device_batch(self, params, n_frames, d_records_ptr, seed_stride=0, stream_ptr=None):
         _check(lib().r1_render_shard_device_batch(self._c, C.byref(params), n_frames, seed_stride, C.c_void_p(d_records_ptr),
-                                                  C.c_void_p(stream_ptr) if stream_ptr else None))
+                                                  _stream_arg(stream_ptr)))
 
     def assemble_device_records_batch(self, params, n_frames, d_gathered_ptr, d_frames_ptr, stream_ptr=None):
         _check(lib().r1_assemble_device_records_batch(self._c, C.byref(params), n_frames, C.c_void_p(d_gathered_ptr), C.c_void_p(d_frames_ptr),
-                                                      C.c_void_p(stream_ptr) if stream_ptr else None))
+                                                      _stream_arg(stream_ptr)))
 
     def render_frame_device(self, params, stream_ptr=None):
         """r1_render_async without host buffers: the frame stays in the context's device buffers (what the copies cost)."""
-        _check(lib().r1_render_async(self._c, C.byref(params), None, None, C.c_void_p(stream_ptr) if stream_ptr else None))
+        _check(lib().r1_render_async(self._c, C.byref(params), None, None, _stream_arg(stream_ptr)))
 
     def render_shard_device(self, params, d_block_ptr, d_rays_ptr, stream_ptr=None):
         _check(lib().r1_render_shard_device(self._c, C.byref(params), C.c_void_p(d_block_ptr), C.c_void_p(d_rays_ptr),
-                                            C.c_void_p(stream_ptr) if stream_ptr else None))
+                                            _stream_arg(stream_ptr)))
 
     def assemble_device(self, params, d_blocks_ptr, d_rgb_ptr, stream_ptr=None):
         _check(lib().r1_assemble_device(self._c, C.byref(params), C.c_void_p(d_blocks_ptr), C.c_void_p(d_rgb_ptr),
-                                        C.c_void_p(stream_ptr) if stream_ptr else None))
+                                        _stream_arg(stream_ptr)))
 
     def assemble_device_strided(self, params, d_blocks_ptr, shard_stride_bytes, d_rgb_ptr, stream_ptr=None):
         _check(lib().r1_assemble_device_strided(self._c, C.byref(params), C.c_void_p(d_blocks_ptr), shard_stride_bytes,
-                                                C.c_void_p(d_rgb_ptr), C.c_void_p(stream_ptr) if stream_ptr else None))
+                                                C.c_void_p(d_rgb_ptr), _stream_arg(stream_ptr)))
 
     def assemble_device_records(self, params, d_records_ptr, d_rgb_ptr, d_total_rays_ptr, stream_ptr=None):
         _check(lib().r1_assemble_device_records(self._c, C.byref(params), C.c_void_p(d_records_ptr), C.c_void_p(d_rgb_ptr),
-                                                C.c_void_p(d_total_rays_ptr), C.c_void_p(stream_ptr) if stream_ptr else None))
+                                                C.c_void_p(d_total_rays_ptr), _stream_arg(stream_ptr)))
 
     def set_pixel_mode(self, on):
         _check(lib().r1_set_pixel_mode(self._c, 1 if on else 0))

@@ -91,8 +91,8 @@ __global__ void __launch_bounds__(R1_BLOCK) r1_wf_shade(const R1WaveArgs W)
             V3 col;
             if (shade_level<true>(W.t, p, __float_as_int(h.y), h.x, nullptr, W.n_paths, slot, (int)threadIdx.x, col))
             {
-                W.t.samples[p.k] = make_float4(col.x, col.y, col.z, __uint_as_float(p.rays));
-                lane_rays += p.rays;
+                W.t.samples[p.k] = make_float4(col.x, col.y, col.z, __uint_as_float(path_rays(p)));
+                lane_rays += path_rays(p);
             }
             else
             {
@@ -316,9 +316,9 @@ extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int 
         return hipErrorInvalidValue;
     if (variant == 3 && big)
         variant = 2; // (no diagnostic build of the LDS-tiled sweep)
-    // the product kernels resolve their tiles themselves (R1_LAND): they need resolver workgroups; the other builds have none
-    const bool land_kernel = R1_LAND && (variant == 2 || variant == 4) && mode != 2;
-    if (land_kernel != (args->land_res > 0u) || (land_kernel && (int)args->land_res >= blocks))
+    // the throughput builds of the product kernels sum their tiles themselves (R1_LAND): a launch through them says on how many XCDs
+    const bool land_kernel = R1_LAND && (variant == 2 || variant == 4) && mode == 0;
+    if (land_kernel != (args->land_res > 0u))
         return hipErrorInvalidValue;
     if (tree)
         return big ? r1_tu_tree_big_launch(args, variant, mode, batch, blocks, trav, stream) : r1_tu_tree_small_launch(args, variant, mode, batch, blocks, trav, stream);

@@ -135,7 +135,6 @@ struct r1_context
     bool land_armed = false;     // the countdowns / accumulators behind the counter block hold the values of land_key
     r1_params land_key;
     int land_frames = 0;
-    size_t land_tail_frames = 0; // frames the allocation's per-launch part was laid out for
     DevBuf batch_rays;  // frame batches: per-frame ray-count accumulators of the resolve launch + its finished-workgroup counter
     int tile_frames = 0; // frames per launch the tile arithmetic below was made for
     bool counters_clean = false; // the last frame's resolve launch zeroed the counter block: the next frame needs no memset
@@ -151,6 +150,7 @@ struct r1_context
     int occupancy[48] = {0}; // [variant + 8 * big + 16 * mode]
     bool pixel_mode = false; // r1_set_pixel_mode
     DevBuf gstack; // blocks per CU of the trace kernel, by variant
+    DevBuf land_spill; // R1_LAND: [waves of the largest grid][136] tiles a wave owes beyond its LDS notes
 
     r1_launch_info info;
 };
@@ -262,7 +262,7 @@ extern "C" void r1_destroy(r1_context *c)
     release(c->sweep), release(c->exact), release(c->shade), release(c->mat), release(c->members);
     release(c->bvh_nodes), release(c->bvh_prims), release(c->bvh_ids);
     release(c->wf_paths), release(c->wf_hits), release(c->wf_queue), release(c->wf_counts);
-    release(c->gstack), release(c->counters), release(c->samples), release(c->image), release(c->batch_rays);
+    release(c->land_spill), release(c->gstack), release(c->counters), release(c->samples), release(c->image), release(c->batch_rays);
     release(c->wave_log);
     if (c->host_word)
         (void)hipHostFree(c->host_word);
@@ -682,7 +682,8 @@ static int ensure_counters(r1_context *c, const r1_params *p, int n_frames)
     if (rc)
         return rc;
     const size_t F = (size_t)(n_frames > 0 ? n_frames : 1);
-    const size_t need = land_frames_off() + ((F * 16 + 127) & ~(size_t)127) + F * (size_t)(c->n_local_tiles ? c->n_local_tiles : 1) * 4 * R1_LAND_CNT_STRIDE;
+    const size_t tiles = F * (size_t)(c->n_local_tiles ? c->n_local_tiles : 1);
+    const size_t need = land_frames_off() + ((F * 16 + 127) & ~(size_t)127) + tiles * 4 * R1_LAND_CNT_STRIDE;
     if (c->counters.p && need <= c->counters.cap)
         return R1_OK;
     R1_HIP(hipStreamSynchronize(c->stream)); // (a frame in flight on another stream is the caller's to order: one frame per context at a time)
@@ -785,7 +786,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     }
     // tiles resolved inside the trace kernel: the product kernels' launches; the diagnostic builds, the reference-form
     // sweep, the wavefront variant and PIXEL mode keep the round-3 form (records + r1_resolve_kernel, or no records at all)
-    const bool land = R1_LAND && (variant == 2 || variant == 4) && !pixel_mode && c->total_samples > 0;
+    const bool land = R1_LAND && (variant == 2 || variant == 4) && mode == 0 && c->total_samples > 0;
     if (!pixel_mode)
     {
         const size_t want = (size_t)(c->total_samples ? c->total_samples : 1) * 16;
@@ -906,22 +907,6 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
         blocks = needed;
     if (blocks < 1)
         blocks = 1;
-    // R1_LAND: resolver workgroups at the front of the grid (`blocks` stays the number of TRACING workgroups).  A frame in flight adds
-    // them to its small grid; a synchronous frame's grid fills the chip, so there they come out of the tracing workgroups' slots.
-    long long n_res = 0;
-    if (land)
-    {
-        static const long long res_tp_env = r1_knob("R1_LAND_RES_TP", R1_LAND_RES_TP), res_sync_env = r1_knob("R1_LAND_RES_SYNC", R1_LAND_RES_SYNC);
-        const long long tiles_all = (long long)c->n_local_tiles * n_frames;
-        n_res = std::max(1LL, std::min(throughput_mode ? res_tp_env : res_sync_env, tiles_all));
-        const long long slots = (long long)c->cus * per_cu;
-        if (!throughput_mode && blocks + n_res > slots)
-        {
-            n_res = std::max(1LL, std::min(n_res, slots / 8));
-            blocks = std::max(1LL, std::min(blocks, slots - n_res));
-        }
-    }
-
     // Queue chunk per atomic: guided (remaining / (2 waves)) between chunk_min and chunk_max.  Large
     // chunks keep a wave on consecutive samples (coherent primary rays, whole sample-record lines)
     // and save atomics — measured at N = 1: 256 -> 1.227 ms, 1024 -> 1.197, 4096 -> 1.231 —
@@ -973,9 +958,9 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     }
     if (land)
     {
-        // Launches alternate between two sets of queue heads; resolver 0 zeroes the set the launch before used, which nobody touches
-        // any more (a wave may still ask its own queue for work after the frame's last tile has been resolved, so a launch cannot
-        // clear its own).  After anything else has run through this context both sets (and the round-3 block) are cleared here.
+        // Launches alternate between two sets of queue heads and wave counts; workgroup 0 zeroes the set the launch before used, which
+        // nobody touches any more (a workgroup that starts late still asks its own queue for work after the frame's last tile has been
+        // summed, so a launch cannot clear its own).  After anything else has run through this context both sets (and the round-3 block) are cleared here.
         if (!c->land_prev)
         {
             R1_HIP(hipMemsetAsync(c->counters.p, 0, R1_COUNTER_BYTES, st));
@@ -996,7 +981,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
             c->land_gen = 1;
         }
         a.land_tag = c->land_gen << 8;
-        a.land_res = (uint32_t)n_res;
+        a.land_res = 1; // (a landing launch: r1_launch_trace checks that the kernel and the launch agree)
         unsigned long long *frame_rays = (unsigned long long *)((char *)c->counters.p + land_frames_off());
         uint32_t *frame_left = (uint32_t *)(frame_rays + n_frames);
         a.land_cnt = (uint32_t *)((char *)frame_rays + (((size_t)n_frames * 16 + 127) & ~(size_t)127)); // (every countdown on a 128-byte line of its own)
@@ -1023,6 +1008,12 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
         a.land.block_layout = (uint32_t)block_layout;
         a.land.inv_spp = (float)(1.0f / p->spp); // rayweek1.cpp:765
         a.land.error = c->host_word_dev ? (uint32_t *)(c->host_word_dev + 1) : nullptr;
+        {
+            const size_t max_blocks = std::max((size_t)blocks, (size_t)c->cus * (size_t)per_cu);
+            if ((rc = ensure(c->land_spill, max_blocks * (R1_BLOCK / 64) * 136 * 4)))
+                return rc;
+            a.land.owed_spill = (uint32_t *)c->land_spill.p;
+        }
         a.num_rays = nullptr;
     }
     hipEvent_t e0 = c->ev0, e1 = c->ev1, e2 = c->ev2;
@@ -1059,7 +1050,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
         R1_HIP(hipMemsetAsync(d_rays, 0, 8, st));
     R1_HIP(hipEventRecord(e0, st));
     if (c->total_samples && variant != 6)
-        R1_HIP(r1_launch_trace(&a, variant, big, mode, (int)(blocks + n_res), st));
+        R1_HIP(r1_launch_trace(&a, variant, big, mode, (int)blocks, st));
     if (c->total_samples && variant == 6)
     {
         // wavefront variant: path state, per-level queues and the attenuation stack live in HBM
@@ -1129,7 +1120,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     c->timing_valid = true;
 
     c->info.blocks = (int32_t)blocks;
-    c->info.resolver_blocks = (int32_t)n_res;
+    c->info.tiles_in_kernel = land ? 1 : 0;
     c->info.threads_per_block = R1_BLOCK;
     c->info.spheres_active = (int32_t)c->n_active;
     c->info.spheres_padded = (int32_t)c->n_padded_scene;
@@ -1606,5 +1597,19 @@ extern "C" int r1_last_launch_info(r1_context *c, r1_launch_info *out)
     if (!c || !out)
         return R1_EINVAL;
     *out = c->info;
+    return R1_OK;
+}
+
+// internal (tools/land_debug.py): the context's counter allocation as it is after the stream has drained
+extern "C" int r1_debug_dump_counters(r1_context *c, void *out, size_t bytes, size_t *have)
+{
+    if (!c || !out || !c->counters.p)
+        return R1_EINVAL;
+    R1_HIP(hipSetDevice(c->device));
+    R1_HIP(hipStreamSynchronize(c->stream));
+    const size_t n = bytes < c->counters.cap ? bytes : c->counters.cap;
+    R1_HIP(hipMemcpy(out, c->counters.p, n, hipMemcpyDeviceToHost));
+    if (have)
+        *have = n;
     return R1_OK;
 }

@@ -28,9 +28,10 @@
 #define R1_GROUP_MAX 4         // spheres per group (level 1 of the sweep tests group bounds)
 #define R1_GROUP_MIN_SPHERES 128 // scenes with fewer active spheres are swept ungrouped
 #define R1_GROUP_RATIO 3.5     // a group's bounding radius stays within this factor of its smallest member radius
-#define R1_SAMPLES_PER_LANE 150    // throughput mode grid sizing: samples each lane should get (see enqueue_frame): 1200x800x10 -> 256
-                                   // workgroups per frame (128 is 2 % better in a long run of 16 frames in flight, 256 is 5 % better over
-                                   // the 20 frames of a short run, whose ramp and drain weigh more) ...
+#define R1_SAMPLES_PER_LANE 100    // throughput mode grid sizing: samples each lane should get (see enqueue_frame): 1200x800x10 -> 380
+                                   // workgroups per frame (round 4, tiles summed in the kernel: 150 / 100 / 80 samples = 254 / 380 / 475 workgroups:
+                                   // 35.4 / 35.2 / 34.3 Grays/s over 300 steps, 32.1 / 33.0 / 32.8 over the driver's 20 — a burst drains better
+                                   // with more, shorter-lived workgroups per frame, a long run loses ~1 % to their drains; round 3 ran 150) ...
 #define R1_MIN_BLOCKS 128          // ... but at least this many workgroups per frame (the per-rank frames of a 4- or 8-GPU run:
                                    // 0.301 ms per frame against 0.329 with 256) ...
 #define R1_SAMPLES_PER_LANE_MIN 32 // ... as long as a lane still gets this many samples
@@ -46,24 +47,16 @@
 #define R1_COUNTER_BYTES 4096  // per-context counter block: queue heads, ray count (+32), drain counts, stats (+128), sub-queues at +1024;
                                // the allocation carries 64 more bytes: the published ray count of the synchronous entry points
 #define R1_COOP_LANES 2        // R1TraceArgs::coop_lanes (one synchronous frame: 2 -> 1.144 ms, 4 -> 1.160, 8 -> 1.193, 16 -> 1.263)
-// Tiles resolved INSIDE the trace kernel (round 4): the first R1TraceArgs::land_res workgroups of the grid do not trace;
-// they wait for tiles whose samples are complete (a per-tile countdown the tracing waves feed), sum each pixel's records in sample order
-// (rayweek1.cpp:762-775) and store the pixels where the frame is wanted — device memory or the caller's page-locked host buffer.
-// No resolve launch, no copy.  0 builds the round-3 form (r1_resolve_kernel after the trace kernel) for A/B measurements.
+// Tiles resolved INSIDE the trace kernel (round 4; r1_trace.hpp has the protocol): the throughput kernels sum every
+// 32 x 32 tile themselves, on the XCD that traced it, and store the pixels where the frame is wanted — device memory or the caller's
+// page-locked host buffer.  No resolve launch, no copy.  0 builds the round-3 form (r1_resolve_kernel after the trace kernel) for A/B.
 #ifndef R1_LAND
 #define R1_LAND 1
 #endif
-#ifndef R1_LAND_RES_TP
-#define R1_LAND_RES_TP 2       // resolver workgroups of a frame in flight (its 254 tracing workgroups share the chip with the other frames')
-#endif
-#ifndef R1_LAND_RES_SYNC
-#define R1_LAND_RES_SYNC 32    // ... of a synchronous frame, whose grid fills the chip (taken from the tracing workgroups)
-#endif
 #define R1_LAND_CNT_STRIDE 32u  // words between two tiles' countdowns: every countdown on its own 128-byte line (an atomic on ONE line sustains ~88 M/s on this chip,
                                // tools/ubench_atomic.hip; the ~40 tiles a synchronous frame's waves work on at a time shared two lines at first: 3.8 ms per frame instead of 1.1)
-#define R1_LAND_WINDOW 16u     // tiles of its own a resolver polls at a time (they complete roughly in order)
-#define R1_LAND_MAX_WAIT (1u << 25) // resolver: polls (~1 us each) without any of its tiles completing, or failed passes over one tile, before it
-                                    // gives up and flags the launch (a miscount would otherwise hang the device instead of failing the call)
+#define R1_LAND_MAX_WAIT (1u << 16) // passes over a claimed tile that still find a record of an earlier launch before the wave gives up and flags the launch
+                                    // (a record's store is on its way for microseconds; a bug would otherwise hang the device instead of failing the call)
 #define R1_COUNTER_TAIL 4096   // behind the R1_COUNTER_BYTES block: +0 published ray count, +64 batch-argument slots (8 x 32 B), +1024 the second
                                // set of queue heads (frames alternate between the sets; the resolvers of a launch zero the set the
                                // launch before it used), then per launch: frame accumulators and the per-tile countdowns
@@ -105,7 +98,7 @@ struct R1BatchArgs
     uint32_t n_local_tiles;
 };
 
-// What the resolver workgroups of a launch need (R1_LAND); by value in the kernel arguments, read on the resolvers' code path only.
+// What the waves that sum finished tiles need (R1_LAND); by value in the kernel arguments, read when a wave has run out of samples.
 struct R1LandArgs
 {
     uint8_t *out;                   // frame 0's pixels: row-major image (block_layout 0) or dense tile block (1); device memory or page-locked host memory
@@ -114,12 +107,13 @@ struct R1LandArgs
     unsigned long long rays_offset; // rays_in_out: frame f's uint64 count at out + f * out_stride + rays_offset
     unsigned long long *frame_rays; // [n_frames] ray-count accumulators (zero between launches)
     uint32_t *frame_left;           // [n_frames] tiles not yet resolved (n_local_tiles between launches)
-    uint32_t *clear_heads;          // queue heads of the set the PREVIOUS launch through this context used: zeroed by resolver 0
-    uint32_t clear_count;           // ... that many heads, 32 words apart
+    uint32_t *clear_heads;          // queue heads and wave counts of the set the PREVIOUS launch through this context used: zeroed by workgroup 0
+    uint32_t clear_count;           // ... that many words, 32 words apart
     uint32_t n_frames;              // frames of the launch (1: a single frame)
     uint32_t rays_in_out, block_layout;
     float inv_spp;                  // (float)(1.0f / spp), rayweek1.cpp:765
-    uint32_t *error;                // page-locked host word (or null): set if a resolver gave up waiting (R1_LAND_MAX_WAIT) — never in a correct run
+    uint32_t *owed_spill;           // [waves of the grid][136]: tiles a wave owes beyond the 24 it notes in LDS
+    uint32_t *error;                // page-locked host word (or null): set if a wave gave up on a tile (R1_LAND_MAX_WAIT) — never in a correct run
 };
 
 // Everything the trace kernel needs; passed by value (kernarg segment => SGPRs).
@@ -199,10 +193,11 @@ struct R1TraceArgs
     int32_t bvh_depth;            // tree kernels: traversal stack entries per thread (dynamic LDS = depth * R1_BLOCK * 4)
     int32_t block_layout;         // PIXEL mode: 1 = `samples` is a dense tile block (pixel index = queue slot), 0 = a row-major image
     float inv_spp;                // PIXEL mode: (float)(1.0f / spp), rayweek1.cpp:765
-    // R1_LAND (tiles resolved inside the kernel): land_res > 0 turns it on for this launch
-    uint32_t land_res;            // workgroups 0 .. land_res - 1 are resolvers, the rest trace
+    // R1_LAND (tiles resolved inside the kernel; the throughput builds of the product kernels)
+    uint32_t land_res;            // 1: a landing launch (the throughput builds take no other)
     uint32_t land_tag;            // launch generation << 8, or-ed into every sample record's ray-count word: a record is the launch's own iff its tag matches
-    uint32_t *land_cnt;           // [n_frames * n_local_tiles] x R1_LAND_CNT_STRIDE words: samples each tile still lacks; the tracing waves subtract, the tile's resolver re-arms
+    uint32_t *land_cnt;           // [n_frames * n_local_tiles] x R1_LAND_CNT_STRIDE words: samples each tile still lacks; the tracing waves subtract, the wave that
+                                  // owes the tile re-arms
     R1LandArgs land;
     uint32_t coop_lanes;          // small scenes: once the queue is empty, a wave with <= coop_lanes live paths tests each of them
                                   // against ALL spheres, 64 at a time across the wave (cooperative_sweep), instead of walking the tree

@@ -123,10 +123,14 @@ struct Path
     V3 o, d;                        // Ray::_origin, Ray::_dir (unit)
     uint32_t s_scalar, s0, s1, s2;  // ThreadData::state, lanes 0..2 of ThreadData::state4
     uint32_t k;                     // local sample index (output slot)
-    uint32_t rays;                  // color() invocations of this sample
+    // (color() invocations of the sample = depth + 1 when the path ends — every level counts one ray, rayweek1.cpp:517, and the depth
+    //  grows by one per level that goes on: path_rays)
     int depth;                      // color()'s depth argument
     int sp;                         // entries on the attenuation stack
 };
+
+// color() invocations of a path that has just ended (shade_level returned true)
+__device__ __forceinline__ uint32_t path_rays(const Path &p) { return (uint32_t)p.depth + 1u; }
 
 // mymath.h:224-235
 __device__ __forceinline__ V3 random_in_unit_sphere(Path &p)
@@ -982,7 +986,6 @@ __device__ __forceinline__ void start_ray(const R1TraceArgs &A, Path &p, const i
     p.s0 = sd.lane0;
     p.s1 = sd.lane1;
     p.s2 = sd.lane2;
-    p.rays = 0;
     p.depth = 0;
     p.sp = 0;
 
@@ -1096,7 +1099,7 @@ __device__ __forceinline__ void path_store(float4 *paths, const uint32_t n, cons
     paths[slot] = make_float4(p.o.x, p.o.y, p.o.z, p.d.x);
     paths[(size_t)n + slot] = make_float4(p.d.y, p.d.z, __uint_as_float(p.s_scalar), __uint_as_float(p.s0));
     paths[2 * (size_t)n + slot] = make_float4(__uint_as_float(p.s1), __uint_as_float(p.s2), __uint_as_float(p.k),
-                                              __uint_as_float(p.rays | ((uint32_t)p.depth << 8) | ((uint32_t)p.sp << 16)));
+                                              __uint_as_float(((uint32_t)p.depth << 8) | ((uint32_t)p.sp << 16)));
 }
 
 // returns false for a void slot
@@ -1109,7 +1112,7 @@ __device__ __forceinline__ bool path_load(const float4 *paths, const uint32_t n,
     p.s1 = __float_as_uint(c.x), p.s2 = __float_as_uint(c.y);
     p.k = __float_as_uint(c.z);
     const uint32_t packed = __float_as_uint(c.w);
-    p.rays = packed & 255u, p.depth = (int)((packed >> 8) & 255u), p.sp = (int)((packed >> 16) & 255u);
+    p.depth = (int)((packed >> 8) & 255u), p.sp = (int)((packed >> 16) & 255u);
     return packed != R1_PATH_VOID;
 }
 
@@ -1121,8 +1124,7 @@ template <bool BIG, int LW = R1_STACK_WORDS>
 __device__ __forceinline__ bool shade_level(const R1TraceArgs &A, Path &p, const int hit, const float t_hit, uint32_t *s_stack,
                                             const uint32_t gstride, const uint32_t gtid, const int tid, V3 &col)
 {
-    ++p.rays; // rayweek1.cpp:517
-    bool done = false;
+    bool done = false; // (this level's ray, rayweek1.cpp:517, is counted through the depth: path_rays)
     col = mk(0, 0, 0);
     if (hit >= 0)
     {
@@ -1200,7 +1202,8 @@ __device__ __forceinline__ bool shade_level(const R1TraceArgs &A, Path &p, const
             }
             else
                 done = true; // Metal::scatter() == false -> Vec3(0,0,0), rayweek1.cpp:432, :528
-            ++p.depth;
+            if (!done)
+                ++p.depth; // (a path that ends here keeps its depth: its rays = depth + 1 whichever way it ends)
         }
         else
             done = true; // depth == MAX_BOUNCES: no scatter, no draws, black (rayweek1.cpp:523-528)
@@ -1253,86 +1256,116 @@ __device__ __forceinline__ bool shade_level(const R1TraceArgs &A, Path &p, const
 }
 
 // ---- tiles resolved inside the trace kernel (R1_LAND) ------------------------------------------------------
-// The reference resolves a pixel where it traced it (rayweek1.cpp:762-775).  Here the samples of a pixel end on different lanes,
-// waves and XCDs, and their fp32 sum must run in sample order, so every sample still leaves a 16-byte record; but the records of a
-// 32 x 32 tile are summed by the trace kernel's own launch as soon as the tile is complete, and the pixels go straight to where the
-// frame is wanted — no second launch waiting for workgroup slots behind persistent waves, no copy.
-//   tracing waves:  record = {r, g, b, rays | tag} with ONE 16-byte write-through store (sc1: the eight XCDs' L2s are not coherent with
-//                   each other; a write-back fence per store costs 100 us, tools/ubench_xcd_visibility.hip), then the finished lanes of
-//                   the wave subtract their number from the tile's countdown (one fire-and-forget device-scope atomic per tile);
-//   resolvers:      workgroups 0 .. land_res - 1.  Resolver r owns tiles r, r + land_res, ...; it polls their countdowns, and sums a tile
-//                   that reads zero: sc1 loads, every record's tag checked against the launch's — the countdown is not ordered after
-//                   the stores it counts, so a record may not have landed yet: the tile is then simply tried again — pixels written,
-//                   the tile's rays added to the frame's count, the countdown re-armed for the next launch.  The resolver of a frame's
-//                   last tile publishes the frame's ray count.
-// The tag also makes the records self-describing across launches: a slot still holding an older launch's record never matches.
-typedef float land_f4 __attribute__((ext_vector_type(4)));
-typedef uint32_t land_u4 __attribute__((ext_vector_type(4)));
-
+// The reference resolves a pixel where it traced it (rayweek1.cpp:762-775).  Here the samples of a pixel end on different lanes and
+// waves, and their fp32 sum must run in sample order, so every sample still leaves a 16-byte record; but the records of a 32 x 32
+// tile are summed by the waves of the trace launch itself, and the pixels go straight to where the frame is wanted (device memory or
+// the caller's page-locked host buffer): no second launch waiting for workgroup slots behind persistent waves, no copy.
+// What makes it cheap is that a tile never leaves its XCD.  The eight XCDs' L2s are not coherent with each other: records traced on
+// one XCD and summed on another must be written through to memory (sc1 stores: +7 % on the tracing loop, measured) and waited for
+// by workgroups that do nothing else (+14 %): profiles/r04/land_cross_xcd_cost_breakdown.txt, the first form of this code.  So:
+//   * a tile belongs to the XCD that CLAIMS it: every XCD has a cursor {tile, next sample slot of that tile} its waves take their chunks
+//     from; the wave that takes a tile's last chunk (or finds no tile installed yet) claims the launch's next unclaimed tile for its
+//     XCD and installs it; waves that meet a used-up tile meanwhile wait for that (microseconds).  Nothing
+//     is assumed about which XCD a workgroup runs on — the dispatcher deals them round-robin, starting wherever the last launch
+//     stopped — and XCDs that run faster simply claim more tiles;
+//   * the waves of an XCD store the records with plain stores and count the samples they finish per tile — in two scalar registers for
+//     the tiles of the wave's current and previous chunk — and subtract the count from the tile's countdown when the wave moves on to
+//     another tile (an atomic per finished sample group and iteration cost 7 %: the vector-memory counter of this chip is in order,
+//     so every iteration's first load waited for the atomic in front of it);
+//   * the subtraction that brings a countdown to zero is unique: that wave OWES the tile.  It notes it (a few words of LDS per wave)
+//     and, when it has run out of work, sums its tiles before it exits — their records sit in this XCD's L2 or in memory, nowhere
+//     else — adds each tile's rays to the frame's count and re-arms the countdown for the next launch.  The wave that takes the
+//     frame's last tile off publishes the ray count.  (A wave whose notes are full takes no more samples: it ends early and pays.)
+//   * every record carries the launch's tag in its ray-count word: a countdown is not ordered after the stores it counts, so a wave
+//     that finds a record of an earlier launch in a tile it owes simply reads the tile again (past the vector L1: sc0 loads).
+// Per launch, behind the queue pointer (one of two sets, zeroed by the launch after): line x = XCD x's cursor (uint64); line 16 = the
+// launch's next unclaimed tile.
 #ifndef R1_LAND_EXP
-#define R1_LAND_EXP 0 // measurements only (make tuning EXTRA=-DR1_LAND_EXP=n; frames are NOT valid): 1 resolvers return at once, 2 and no countdown atomics, 3 and plain stores
+#define R1_LAND_EXP 0 // measurements only (make tuning EXTRA=-DR1_LAND_EXP=n; frames are NOT valid): 1 no tile is resolved, 2 and no countdown atomics
 #endif
-__device__ __forceinline__ void land_store(float4 *dst, const V3 col, const uint32_t w)
+#define R1_LAND_OWED 24u        // tiles a wave can owe: words of LDS per wave ...
+#define R1_LAND_OWED_SPILL 136u // ... and of its row in the spill area behind them
+#define R1_LAND_LOADS 10     // records of one pixel a lane keeps in flight while it sums a tile
+#define R1_LAND_MAX_XCD 8u
+
+__device__ __forceinline__ uint32_t xcc_id() { return (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u; } // HW_REG_XCC_ID[3:0]
+
+// What a wave knows about the tiles it works on — kept in LDS (a row of R1_LAND_ROW words per wave), NOT in registers: the tracing loop
+// is at its register budget, and every wave-uniform value carried around it cost spilled scalar registers, whose lanes take a
+// vector register from the loop (five such values: +6.5 % per frame, profiles/r04/land_xcd_local_steps.txt).
+//   [0] t0, [1] n0: tile of the wave's current chunk, samples of it the wave has finished since it last subtracted
+//   [2] t1, [3] n1: the same for the previous chunk's tile
+//   [4] owed: tiles this wave brought to zero and has not summed yet; [8 ...]: their indices (the first R1_LAND_OWED of them)
+#define R1_LAND_ROW 32u
+
+// tile t has been brought to zero by this lane's subtraction: the wave owes it
+__device__ __forceinline__ void land_note(const R1TraceArgs &A, uint32_t *row, const uint32_t t)
 {
-    const land_f4 v = {col.x, col.y, col.z, __uint_as_float(w)};
-#if R1_LAND_EXP >= 3
-    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
-#else
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
-#endif
+    const uint32_t at = atomicAdd(&row[4], 1u); // (LDS)
+    // (past R1_LAND_OWED the wave's row of the spill area.  A wave stops taking samples at R1_LAND_OWED - 3 owed tiles, and what it
+    //  then still finishes — at most the 64 paths and 64 spare samples it holds — cannot bring more than that many tiles to zero)
+    if (at < R1_LAND_OWED)
+        row[8u + at] = t;
+    else if (at < R1_LAND_OWED + R1_LAND_OWED_SPILL)
+        A.land.owed_spill[(size_t)(blockIdx.x * (R1_BLOCK / 64) + (threadIdx.x >> 6)) * R1_LAND_OWED_SPILL + (at - R1_LAND_OWED)] = t;
+    else if (A.land.error)
+        *A.land.error = 1u;
 }
 
-// the lanes with `fin` have just stored the record of sample slot k: count them into their tiles' countdowns (usually one tile per wave
-// and iteration; a wave between two chunks, or one that ends an old path, has two).  Called by all 64 lanes.
-__device__ __forceinline__ void land_count(const R1TraceArgs &A, const bool fin, const uint32_t k, const int lane)
+// subtract n finished samples from tile t's countdown; whoever reaches zero owes the tile.  ONE lane.
+__device__ __forceinline__ void land_flush(const R1TraceArgs &A, uint32_t *row, const uint32_t t, const uint32_t n)
 {
-    unsigned long long rest = __ballot(fin);
-    if (rest == 0ull || R1_LAND_EXP >= 2)
+    if (n == 0u || R1_LAND_EXP >= 2)
         return;
-    const uint32_t j = fastdiv(k, A.div_full); // tile of the launch: k = (j spp + s) tile_px + pix
-    do
-    {
-        const int l = __ffsll((long long)rest) - 1;
-        const uint32_t j0 = (uint32_t)__builtin_amdgcn_readlane((int)j, l);
-        const unsigned long long same = __ballot(fin && j == j0);
-        if (lane == l)
-            (void)__hip_atomic_fetch_sub(A.land_cnt + j0 * R1_LAND_CNT_STRIDE, (uint32_t)__popcll(same), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        rest &= ~same;
-    } while (rest);
+    if (__hip_atomic_fetch_sub(A.land_cnt + t * R1_LAND_CNT_STRIDE, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n)
+        land_note(A, row, t);
 }
 
-// One tile of the launch (t = frame * n_local_tiles + local tile) by the whole workgroup: false if a record did not carry the launch's
-// tag (nothing is accounted then; pixels written from such a pass are overwritten by the pass that succeeds — the host sees the
-// buffer only after the kernel).  Same arithmetic and order as r1_resolve_kernel = rayweek1.cpp:762-775.  A thread keeps up to
-// R1_LAND_LOADS records of ONE pixel in flight (a resolver is bound by the latency of its loads, which go to memory: sc1).
-#define R1_LAND_LOADS 10
-#define R1_LAND_FRAMES_LDS 32 // frames of a batch whose counts a resolver accumulates in LDS (larger batches: atomics per tile)
-struct LandShared
+// this lane has just stored the record of sample slot k: one more finished sample of its tile.  Per lane, no wave-uniform state.
+__device__ __forceinline__ void land_count(const R1TraceArgs &A, uint32_t *row, const uint32_t k)
 {
-    unsigned long long ready;                          // tiles of the resolver's window the last poll found complete (0: gave up)
-    unsigned long long part[4];                        // per-wave partial ray counts of the tile in hand
-    unsigned long long frame_rays[R1_LAND_FRAMES_LDS]; // this resolver's share of each frame's ray count ...
-    uint32_t frame_tiles[R1_LAND_FRAMES_LDS];          // ... and the tiles it stands for
-};
+    const uint32_t j = fastdiv(k, A.div_full); // tile of the launch: k = (j spp + s) tile_px + pix
+    if (j == row[0])
+        atomicAdd(&row[1], 1u); // (LDS)
+    else if (j == row[2])
+        atomicAdd(&row[3], 1u);
+    else
+        land_flush(A, row, j, 1u); // (rare: a path that outlived two chunks)
+}
 
-__device__ __forceinline__ bool land_resolve_tile(const R1TraceArgs &A, const uint32_t t, LandShared &sh)
+// the wave's next chunk comes from tile t.  ONE lane.
+__device__ __forceinline__ void land_chunk(const R1TraceArgs &A, uint32_t *row, const uint32_t t)
+{
+    const uint32_t t0 = row[0];
+    if (t == t0)
+        return;
+    land_flush(A, row, row[2], row[3]);
+    row[2] = t0, row[3] = row[1];
+    row[0] = t, row[1] = 0u;
+}
+
+// One tile of the launch (t = frame * n_local_tiles + local tile) by ONE wave, lane l taking pixels l, l + 64, ...: false if a record
+// did not carry the launch's tag (nothing is accounted then; pixels written from such a pass are overwritten by the pass that
+// succeeds — the host sees the buffer only after the kernel).  Same arithmetic and order as r1_resolve_kernel = rayweek1.cpp:762-775.
+__device__ __forceinline__ bool land_resolve_tile(const R1TraceArgs &A, const uint32_t t, const int lane)
 {
     const R1LandArgs &L = A.land;
-    const int tid = (int)threadIdx.x;
     const uint32_t f = t / A.n_local_tiles, lt = t - f * A.n_local_tiles;
     const uint32_t tile = (uint32_t)A.shard + lt * (uint32_t)A.num_shards;
     const uint32_t ty = tile / (uint32_t)A.tiles_x, tx = tile - ty * (uint32_t)A.tiles_x;
     const int x0 = (int)tx * A.tile_w, y0 = (int)ty * A.tile_h;
     const int tw = min(A.tile_w, A.width - x0), th = min(A.tile_h, A.height - y0);
     const uint32_t tile_px = (uint32_t)(A.tile_w * A.tile_h);
-    // the tile's records [s][pixel] through a buffer resource: 16-byte loads with the sc1 bit (they must not be served from this XCD's L2)
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(A.samples + (size_t)t * A.full), 0, (int)(A.full * 16u), 0x00020000);
-    constexpr int SC1 = 16;
+    // the tile's records [s][pixel], read with sc0 loads (buffer form: 16 bytes at once): they must come from the L2, not from this CU's
+    // vector L1 — a pass that meets a record whose store is still on its way would otherwise find the same stale line again
+    const __amdgpu_buffer_rsrc_t rec = __builtin_amdgcn_make_buffer_rsrc((void *)(A.samples + (size_t)t * A.full), 0, (int)(A.full * 16u), 0x00020000);
+    constexpr int SC0 = 1;
+    typedef uint32_t land_u4 __attribute__((ext_vector_type(4)));
     uint8_t *const out = L.out + (size_t)f * L.out_stride;
     const uint32_t spp = (uint32_t)A.spp;
     uint32_t bad = 0;
     unsigned long long rays = 0;
-    for (uint32_t pix = (uint32_t)tid; pix < tile_px; pix += R1_BLOCK)
+    for (uint32_t pix = (uint32_t)lane; pix < tile_px; pix += 64u)
     {
         const int ly = (int)(pix / (uint32_t)A.tile_w), lx = (int)(pix - (uint32_t)ly * (uint32_t)A.tile_w);
         if (lx >= tw || ly >= th)
@@ -1345,7 +1378,7 @@ __device__ __forceinline__ bool land_resolve_tile(const R1TraceArgs &A, const ui
 #pragma unroll
             for (uint32_t u = 0; u < R1_LAND_LOADS; ++u)
                 if (u < n)
-                    v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((s0 + u) * tile_px + pix) * 16u), 0, SC1);
+                    v[u] = __builtin_amdgcn_raw_buffer_load_b128(rec, (int)(((s0 + u) * tile_px + pix) * 16u), 0, SC0);
 #pragma unroll
             for (uint32_t u = 0; u < R1_LAND_LOADS; ++u)
                 if (u < n)
@@ -1362,121 +1395,62 @@ __device__ __forceinline__ bool land_resolve_tile(const R1TraceArgs &A, const ui
         out[o + 1] = (uint8_t)(int)(cg * 255.99f);
         out[o + 2] = (uint8_t)(int)(cb * 255.99f);
     }
+    if (__ballot(bad != 0u))
+        return false;
     for (int off = 32; off > 0; off >>= 1)
         rays += __shfl_down(rays, off, 64);
-    if ((tid & 63) == 0)
-        sh.part[tid >> 6] = rays;
-    const bool good = __syncthreads_or(bad != 0u) == 0; // (also the barrier between part's writes and its read)
-    if (good && tid == 0)
+    if (lane == 0)
     {
-        const unsigned long long tile_rays = sh.part[0] + sh.part[1] + sh.part[2] + sh.part[3];
         __hip_atomic_store(A.land_cnt + t * R1_LAND_CNT_STRIDE, (uint32_t)(tw * th) * spp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // re-armed for the next launch
-        if (L.n_frames <= R1_LAND_FRAMES_LDS)
-            sh.frame_rays[f] += tile_rays, sh.frame_tiles[f] += 1u; // (published when the resolver is through with its tiles: land_publish)
-        else
+        // the tile's rays, then one tile less to go: the second atomic is issued only when the first has been performed, so whoever
+        // takes the frame's last tile off finds every tile's rays added — and publishes the count (rayweek1.cpp:809-813)
+        const unsigned long long before = __hip_atomic_fetch_add(L.frame_rays + f, rays, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(before));
+        const uint32_t left = __hip_atomic_fetch_sub(L.frame_left + f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left == 1u)
         {
-            // the tile's rays, then one tile less to go: the second atomic is issued only when the first has been performed
-            const unsigned long long before = __hip_atomic_fetch_add(L.frame_rays + f, tile_rays, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("" ::"v"(before));
-            const uint32_t left = __hip_atomic_fetch_sub(L.frame_left + f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (left == 1u)
-            {
-                const unsigned long long total = __hip_atomic_exchange(L.frame_rays + f, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                *(L.rays_in_out ? (unsigned long long *)(out + L.rays_offset) : L.rays_dst) = total; // rayweek1.cpp:809-813
-                __hip_atomic_store(L.frame_left + f, A.n_local_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            const unsigned long long total = __hip_atomic_exchange(L.frame_rays + f, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *(L.rays_in_out ? (unsigned long long *)(out + L.rays_offset) : L.rays_dst) = total;
+            __hip_atomic_store(L.frame_left + f, A.n_local_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // as the next launch expects it
         }
     }
-    __syncthreads(); // part is reused by the next tile
-    return good;
+    return true;
 }
 
-// A resolver's share of frame f's count joins the frame's: its rays, then its tiles — the second atomic is issued only when the first
-// has been performed, so whoever takes the frame's last tiles off finds every share added — and that one publishes the count
-// (rayweek1.cpp:809-813) and leaves the accumulators as the next launch expects them.
-__device__ __forceinline__ void land_publish(const R1TraceArgs &A, const uint32_t f, const unsigned long long rays, const uint32_t tiles)
+// A tracing wave has run out of work: what it still has to subtract, then the tiles it owes.
+__device__ __forceinline__ void land_exit(const R1TraceArgs &A, uint32_t *row, const int lane)
 {
-    const R1LandArgs &L = A.land;
-    const unsigned long long before = __hip_atomic_fetch_add(L.frame_rays + f, rays, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("" ::"v"(before));
-    const uint32_t left = __hip_atomic_fetch_sub(L.frame_left + f, tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (left == tiles)
-    {
-        const unsigned long long total = __hip_atomic_exchange(L.frame_rays + f, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *(L.rays_in_out ? (unsigned long long *)(L.out + (size_t)f * L.out_stride + L.rays_offset) : L.rays_dst) = total;
-        __hip_atomic_store(L.frame_left + f, A.n_local_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// the life of a resolver workgroup (blockIdx.x < A.land_res); all R1_BLOCK threads.  (Inlined: as a called function it turns the
-// kernel's scalar spills into scratch traffic and its arguments into flat loads — 660 bytes of scratch per lane.)
-__device__ __forceinline__ void land_resolver(const R1TraceArgs &A)
-{
-    __shared__ LandShared sh;
-    const R1LandArgs &L = A.land;
-    const int tid = (int)threadIdx.x, lane = tid & 63;
-    const uint32_t r = blockIdx.x, R = A.land_res;
-    const uint32_t tiles_all = A.n_local_tiles * L.n_frames;
-    const uint32_t owned = r < tiles_all ? (tiles_all - r + R - 1u) / R : 0u; // tiles r, r + R, ...
-    // the queue heads the launch before this one used (the other set): nobody touches them during this launch
-    if (r == 0u && (uint32_t)tid < L.clear_count)
-        L.clear_heads[32u * (uint32_t)tid] = 0u;
     if (R1_LAND_EXP)
         return;
-    if (tid < R1_LAND_FRAMES_LDS)
-        sh.frame_rays[tid] = 0ull, sh.frame_tiles[tid] = 0u;
-    uint32_t cursor = 0;         // owned tiles [0, cursor) are done
-    unsigned long long done = 0; // bit i: owned tile cursor + i is done (the tiles of a frame complete roughly, not exactly, in order)
-    uint32_t fails = 0;          // passes in a row that found a record without the launch's tag
-    bool gave_up = false;
-    while (cursor < owned)
+    if (lane == 0)
     {
-        if (tid < 64)
+        land_flush(A, row, row[2], row[3]);
+        land_flush(A, row, row[0], row[1]);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): (the spill area's stores)
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t owed = min((uint32_t)__builtin_amdgcn_readfirstlane((int)row[4]), R1_LAND_OWED + R1_LAND_OWED_SPILL);
+    for (uint32_t i = 0; i < owed; ++i)
+    {
+        uint32_t t; // (two loads kept apart: a select between an LDS and a global address becomes a generic load)
+        if (i < R1_LAND_OWED)
         {
-            unsigned long long ready;
-            uint32_t polls = 0;
-            for (;;)
+            t = row[8u + i];
+            asm volatile("" : "+v"(t));
+        }
+        else
+            t = A.land.owed_spill[(size_t)(blockIdx.x * (R1_BLOCK / 64) + (threadIdx.x >> 6)) * R1_LAND_OWED_SPILL + (i - R1_LAND_OWED)];
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        // a record whose store is still on its way (the countdown is not ordered after the stores) shows an old tag: read again
+        uint32_t tries = 0;
+        while (!land_resolve_tile(A, t, lane))
+            if (++tries == R1_LAND_MAX_WAIT)
             {
-                const uint32_t i = cursor + (uint32_t)lane;
-                const bool in = (uint32_t)lane < R1_LAND_WINDOW && i < owned && !((done >> lane) & 1ull);
-                uint32_t c = 1u;
-                if (in)
-                    c = __hip_atomic_load(A.land_cnt + (i * R + r) * R1_LAND_CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ready = __ballot(in && c == 0u);
-                if (ready || ++polls == R1_LAND_MAX_WAIT)
-                    break;
-                __builtin_amdgcn_s_sleep(64); // ~2 us
+                if (lane == 0 && A.land.error)
+                    *A.land.error = 1u; // never in a correct run; the host reports the launch as failed
+                break;
             }
-            if (lane == 0)
-                sh.ready = ready;
-        }
-        __syncthreads();
-        unsigned long long todo = sh.ready;
-        if (todo == 0ull || fails >= R1_LAND_MAX_WAIT)
-        {
-            gave_up = true;
-            break;
-        }
-        while (todo) // every tile the poll found complete (a resolve ends with a barrier: sh.ready is not rewritten before all have read it)
-        {
-            const int b = __ffsll((long long)todo) - 1;
-            todo &= todo - 1ull;
-            if (land_resolve_tile(A, (cursor + (uint32_t)b) * R + r, sh))
-                done |= 1ull << b, fails = 0;
-            else
-                ++fails; // a record of the tile was still on its way: the next poll offers the tile again
-        }
-        while (done & 1ull)
-            done >>= 1, ++cursor;
     }
-    if (gave_up)
-    {
-        if (tid == 0 && L.error)
-            *L.error = 1u; // the host reports the launch as failed (r1_sync / r1_render) and re-arms the countdowns
-        return;
-    }
-    if (L.n_frames <= R1_LAND_FRAMES_LDS && (uint32_t)tid < L.n_frames && sh.frame_tiles[tid])
-        land_publish(A, (uint32_t)tid, sh.frame_rays[tid], sh.frame_tiles[tid]);
 }
 
 } // namespace
@@ -1513,16 +1487,21 @@ template <int VARIANT, bool STATS, bool BIG, int MODE>
 __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MODE>::value)) r1_trace_kernel(const R1TraceArgs A)
 {
     constexpr bool LAT = MODE == 1, PIX = MODE == 2, BATCH = MODE == 3; // MODE 3 = MODE 0 whose queue spans the frames of a batch
-    // tiles resolved inside the kernel: the product kernels (not the diagnostic builds, PIXEL mode or the reference-form
-    // sweep); a launch through them has land_res >= 1 (r1_launch_trace checks)
-    constexpr bool LAND = R1_LAND && !STATS && !PIX && VARIANT != 1;
-    const uint32_t n_res = LAND ? A.land_res : 0u; // resolver workgroups at the front of the grid
-    if (LAND && blockIdx.x < n_res)
-    {
-        land_resolver(A);
-        return;
-    }
-    const uint32_t tb = blockIdx.x - n_res, n_tb = gridDim.x - n_res; // this tracing workgroup, of so many
+    // tiles resolved inside the kernel: the throughput builds of the product kernels (frames in flight, MODE 0 / 3); a
+    // launch through them is a landing launch (r1_launch_trace checks).  The synchronous frame keeps the resolve launch: its tiles would
+    // have to be dealt to the XCDs dynamically (the XCDs of one chip run this kernel up to 20 % apart), see DESIGN.md §4.10.
+    constexpr bool LAND = R1_LAND && !STATS && (MODE == 0 || MODE == 3) && VARIANT != 1;
+    const uint32_t tb = blockIdx.x, n_tb = gridDim.x;
+    // LAND: this workgroup's XCD (HW_REG_XCC_ID), the tiles of the launch
+    const uint32_t xcd = LAND ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(xcc_id() & 7u)) : 0u;
+    const uint32_t land_tiles = LAND ? A.total_samples / A.full : 0u;
+#ifdef R1_LAND_DEBUG
+    if (LAND && threadIdx.x == 0 && blockIdx.x < 8)
+        A.queue[32u * (17u + blockIdx.x % 7u)] = 0x1000u | (xcc_id() << 4) | xcd; // (tools/land_debug.py)
+#endif
+    if (LAND && blockIdx.x == 0) // the cursors / wave counts the launch BEFORE this one used: nobody touches them during this launch
+        for (uint32_t i = threadIdx.x; i < 32u * A.land.clear_count; i += R1_BLOCK)
+            A.land.clear_heads[i] = 0u;
     typedef typename IdxType<BIG>::type IDX;
     unsigned long long wstat[18];
     if (STATS)
@@ -1584,7 +1563,7 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
     Path p;
     p.o = mk(0, 0, 0), p.d = mk(0, 0, 0);
     p.s_scalar = p.s0 = p.s1 = p.s2 = 1;
-    p.k = 0, p.rays = 0, p.depth = 0, p.sp = 0;
+    p.k = 0, p.depth = 0, p.sp = 0;
     bool alive = false;
     Pixel px; // PIXEL mode: the pixel this lane owns
     px.acc = mk(0, 0, 0), px.xy = 0, px.off = 0, px.s = (uint32_t)A.spp;
@@ -1613,10 +1592,16 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
     // wave-uniform queue state.  Chunks shrink as the queue drains (guided self-scheduling):
     // a wave asks for ~1/(2*waves) of what it last saw remaining, between R1_CHUNK_MIN and
     // R1_CHUNK samples, so that the last waves to finish hold little work.
+    // LAND: chunks come from the cursor of this XCD (A.queue + 32 xcd, see above); q_next / q_end are sample slots of the launch either way
     uint32_t q_next = 0, q_end = 0;
     const uint32_t q_total = A.total_samples;
     uint32_t q_remaining = q_total;
     const uint32_t n_waves2 = 2u * n_tb * (R1_BLOCK / 64);
+    uint32_t *const q_head = LAND ? A.queue + 32u * xcd : A.queue;
+    __shared__ uint32_t s_land[LAND ? (R1_BLOCK / 64) * R1_LAND_ROW : 1];
+#define row (s_land + (LAND ? (threadIdx.x >> 6) * R1_LAND_ROW : 0u)) /* this wave's row (see land_count); recomputed where it is used: one register less around the loop */
+    if (LAND && lane < 8)
+        row[lane] = (lane == 0 || lane == 2) ? 0xFFFFFFFFu : 0u;
     bool exhausted = false;
     // sub-queue this wave pulls from (A.nq > 1), wave-uniform
     // (workgroups b .. b + 7 sit on the eight XCDs and share their sub-queues, so every sub-queue is served from
@@ -1639,7 +1624,7 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
         if (SPARE && !alive && has_spare)
         {
             p.o = spare.o, p.d = spare.d, p.s_scalar = spare.s_scalar, p.s0 = spare.s0, p.s1 = spare.s1, p.s2 = spare.s2, p.k = spare.k;
-            p.rays = 0, p.depth = 0, p.sp = 0;
+            p.depth = 0, p.sp = 0;
             alive = true, has_spare = false;
             trav_start(tv);
         }
@@ -1664,11 +1649,60 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
                         base = atomicAdd(A.queue + 32u * home, 1u);
                     base = (__builtin_amdgcn_readfirstlane(base) * A.nq + home) * want;
                 }
+                else if (LAND && (uint32_t)__builtin_amdgcn_readfirstlane((int)row[4]) + 3u >= R1_LAND_OWED)
+                    base = q_total; // this wave's notes of owed tiles are (nearly) full: it takes no more samples, ends early and sums them
+                else if (LAND)
+                {
+                    // guided as the single queue is: ~ what is left of the launch / (2 waves) — here: the tiles nobody has claimed yet
+                    want = min(A.chunk_max, max(A.chunk_min, q_remaining / n_waves2));
+                    base = q_total; // (exhausted unless a chunk is found)
+                    for (;;)
+                    {
+                        unsigned long long old = 0;
+                        if (lane == 0)
+                            old = __hip_atomic_fetch_add((unsigned long long *)q_head, (unsigned long long)want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(old >> 32)); // tile + 1; 0: none installed yet; ~0: none left
+                        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)old);          // slots of the tile handed out before this call
+                        if (hi == 0xFFFFFFFFu)
+                            break;
+                        const bool have = hi != 0u && lo < A.full;
+                        const bool advance = (hi == 0u && lo == 0u) || (have && lo + want >= A.full); // exactly one wave per installed tile (and per XCD at the start)
+                        if (advance && lane == 0)
+                        {
+                            const uint32_t g = __hip_atomic_fetch_add(A.queue + 32u * 16u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            unsigned long long nv = 0xFFFFFFFFull << 32;
+                            if (g < land_tiles)
+                                nv = (unsigned long long)(g + 1u) << 32;
+                            (void)__hip_atomic_exchange((unsigned long long *)q_head, nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        if (have)
+                        {
+                            base = (hi - 1u) * A.full + lo;
+                            want = min(want, A.full - lo);
+                            q_remaining = (land_tiles - min(land_tiles, hi)) * A.full; // (the tiles behind this one: what the next call is guided by)
+                            if (lane == 0)
+                                land_chunk(A, row, hi - 1u);
+                            break;
+                        }
+                        if (advance)
+                            continue; // installed the XCD's first tile myself: take from it
+                        // a used-up tile (or none yet): the wave that installs the next one is a few atomics away
+                        for (;;)
+                        {
+                            __builtin_amdgcn_s_sleep(16);
+                            unsigned long long now = 0;
+                            if (lane == 0)
+                                now = __hip_atomic_load((unsigned long long *)q_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(now >> 32)) != hi)
+                                break;
+                        }
+                    }
+                }
                 else
                 {
                     want = min(A.chunk_max, max(A.chunk_min, q_remaining / n_waves2));
                     if (lane == 0)
-                        base = atomicAdd(A.queue, want);
+                        base = atomicAdd(q_head, want);
                     base = __builtin_amdgcn_readfirstlane(base);
                 }
                 if (base >= q_total)
@@ -1684,7 +1718,8 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
                 }
                 q_next = base;
                 q_end = min(base + want, q_total);
-                q_remaining = q_total - q_end;
+                if (!LAND)
+                    q_remaining = q_total - q_end;
             }
             const uint32_t avail = q_end - q_next;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
@@ -1715,7 +1750,7 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
         if (SPARE && !alive && has_spare) // the lanes that had died without a spare start on the one they just got
         {
             p.o = spare.o, p.d = spare.d, p.s_scalar = spare.s_scalar, p.s0 = spare.s0, p.s1 = spare.s1, p.s2 = spare.s2, p.k = spare.k;
-            p.rays = 0, p.depth = 0, p.sp = 0;
+            p.depth = 0, p.sp = 0;
             alive = true, has_spare = false;
             trav_start(tv);
         }
@@ -1793,18 +1828,18 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
                         pixel_write(A, px);
                 }
                 else if (LAND)
-                    land_store(A.samples + p.k, col, p.rays | A.land_tag);
+                    A.samples[p.k] = make_float4(col.x, col.y, col.z, __uint_as_float(path_rays(p) | A.land_tag));
                 else
-                    A.samples[p.k] = make_float4(col.x, col.y, col.z, __uint_as_float(p.rays));
+                    A.samples[p.k] = make_float4(col.x, col.y, col.z, __uint_as_float(path_rays(p)));
                 if (!LAND)
-                    lane_rays += p.rays; // (LAND: the resolvers add up the records' counts)
+                    lane_rays += path_rays(p); // (LAND: the waves that sum the tiles add up the records' counts)
                 alive = false, fin = true;
             }
             else if (VARIANT == 4)
                 trav_start(tv); // the scattered ray starts its walk at the root
         }
-        if (LAND)
-            land_count(A, fin, p.k, lane);
+        if (LAND && fin)
+            land_count(A, row, p.k);
         if (STATS)
             wstat[7] += __builtin_readcyclecounter() - wstat[15];
     }
@@ -1851,6 +1886,9 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
         }
     }
 
+    if (LAND)
+        land_exit(A, row, lane);
+#undef row
     // ray count: wave reduction, one atomic per wave (rayweek1.cpp:809-813)
     if (!LAND)
     {
