@@ -10,11 +10,13 @@
 A "step" is one full frame of the workload, from dispatch to PIXELS AND RAY COUNT ON THE HOST — the span the
 reference's Timer covers (rayweek1.cpp:848 -> :891): every rank traces + resolves the tiles it owns (tile t -> rank
 t % N, include/rays1.h r1_params.shard); at N > 1 the per-rank records (dense tile block + 8-byte ray count) are
-all-gathered with RCCL (torch.distributed "nccl") — ONE collective per frame — and assembled; then the row-major image
-and the frame's ray count are copied into page-locked host memory on the frame's own stream.  Several frames are in
-flight (one stream + context + host buffer each), and the timed region ends when every frame's copy has landed.
+all-gathered with RCCL (torch.distributed "nccl") — ONE collective per frame — and assembled, and the row-major image and the
+frame's ray count are copied into page-locked host memory on the frame's own stream.  At N = 1 a frame is ONE launch: the trace
+kernel sums every 32 x 32 tile on the XCD that traced it and stores the pixels and the ray count straight into the page-locked
+frame (no resolve launch, no copy).  Several frames are in flight (one stream + context + host buffer each),
+and the timed region ends when every frame has landed.
 The frame is fixed (BASELINE: large scene, 1200x800x10 spp), so scaling is STRONG.  Inputs (sphere tables, camera)
-are resident in HBM before the timed region.  `value_device_resident` is the same run without the copies to the host
+are resident in HBM before the timed region.  `value_device_resident` is the same run with the frames left in HBM
 (round 2's headline); `value_dispatch_to_host` is ONE synchronous frame at a time through r1_render() — what the
 drop-in's benchmark() prints.  Data is synthetic by construction: the scenes are code, not files.
 """
@@ -42,6 +44,15 @@ INFLIGHT_SINGLE, QUEUES_SINGLE = 20, 20
 INFLIGHT_RANK, QUEUES_RANK = 10, 12
 INFLIGHT_RANK_BATCHED = 8   # launches in flight per rank when every launch carries a batch of N >= 3 frames
 QUEUES_CLIFF = 24
+
+
+def lib_sha16(path):
+    """First 16 hex digits of the sha256 of a librays1 build (what profiles/pmc_traffic.json is keyed on)."""
+    import hashlib
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
 
 
 def cpu_model():
@@ -491,7 +502,7 @@ def run_ranks(args):
             self.last = k
             sp = self.stream.cuda_stream
             if not (sharded or args.pixel_mode):
-                # whole frames on this GPU: trace + resolve straight into row-major frame records, then ONE copy to the host
+                # whole frames on this GPU: ONE launch that traces, sums its tiles and stores them into the page-locked frame records
                 if B == 1:
                     self.rend.render_async(p, self.host, sp) if host_copy[0] else self.rend.render_frame_device(p, sp)
                 else:
@@ -695,12 +706,17 @@ def run_ranks(args):
                        6: "wavefront: generate / intersect / shade kernels, box tree (comparison build)"}[info["kernel"]]
         kernel_s = trace_ms_sum / max(launches, 1) * 1e-3  # average launch duration, HIP events on the stream of each launch
         overlap = trace_ms_sum * 1e-3 / elapsed           # launches of different frames overlap (frames in flight)
-        traffic, traffic_source, valu_instr, valu_source, valu_lanes, valu_busy = None, None, None, None, None, None
+        traffic, traffic_source, valu_instr, valu_source, valu_lanes, valu_busy, pmc_note = None, None, None, None, None, None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath) and info["kernel"] != 6:
             try:
                 tj = json.load(open(tpath))
-                if tj.get("workload") == f"{args.scene} {w}x{h}x{spp}" and n == 1 and not sharded and tj.get("kernel_variant") == info["kernel"]:
+                # counters are only quoted for the build they were measured with: the file records the library's hash
+                lib_now = lib_sha16(binding.lib_path())
+                if tj.get("lib_sha16") != lib_now:
+                    pmc_note = (f"profiles/pmc_traffic.json was measured with another build of librays1.so ({tj.get('lib_sha16')}, running {lib_now}): "
+                                "not quoted; tools/profile_round.sh refreshes it")
+                elif tj.get("workload") == f"{args.scene} {w}x{h}x{spp}" and n == 1 and not sharded and tj.get("kernel_variant") == info["kernel"]:
                     traffic = tj.get("hbm_bytes_per_launch")
                     traffic_source = f"profiles/pmc_traffic.json: {tj.get('source', 'rocprofv3 --pmc passes')} (not measured by this run)"
                     valu_instr = tj.get("valu_wave_instructions_per_launch")
@@ -722,7 +738,7 @@ def run_ranks(args):
             "bound": "valu", "peak": FP32_VECTOR_PEAK_TF, "unit": "TFLOP/s",
             "achieved": agg,
             "frac": (agg / FP32_VECTOR_PEAK_TF) if agg else None,
-            "traffic": traffic, "traffic_source": traffic_source,
+            "traffic": traffic, "traffic_source": traffic_source, "traffic_note": pmc_note,
             "kernel": "r1_trace_kernel" if info["kernel"] != 6 else "r1_wf_generate + 51 x (r1_wf_intersect, r1_wf_shade)",
             "flop_per_frame": flop_frame, "flop_per_launch": flop, "frames_per_launch": frames / max(launches, 1),
             "work": work,
@@ -756,9 +772,11 @@ def run_ranks(args):
         cfg.update({
             "parallelism": f"tile-split x{n}" + (" + one RCCL all-gather per frame (pixels + ray counts)" if n > 1 else ""),
             "value_mode": (f"{len(slots) * B} frames in flight = {len(slots)} launches (one stream + context each) x {B} frames per launch, "
-                           f"scene resident in HBM; every frame ends with its pixels + ray count copied to page-locked HOST memory "
-                           f"({host_mb:.2f} MB per frame) on its launch's stream, and the timed region ends when all copies have landed "
-                           "(rayweek1.cpp:848 -> :891, pipelined)") if host_copy[0] else
+                           f"scene resident in HBM; every frame ends with its pixels + ray count in page-locked HOST memory "
+                           f"({host_mb:.2f} MB per frame) — " + ("stored there tile by tile by the trace launch itself (no resolve launch, no copy)"
+                                                               if info.get("tiles_in_kernel") and not (sharded or args.pixel_mode) else
+                                                               "copied on its launch's stream") +
+                           ", and the timed region ends when all frames have landed (rayweek1.cpp:848 -> :891, pipelined)") if host_copy[0] else
                           f"{len(slots) * B} frames in flight ({len(slots)} launches x {B} frames), scene and images resident in HBM",
             "workgroups": info["blocks"], "threads_per_workgroup": info["threads_per_block"],
             "frames_in_flight": len(slots) * B, "launches_in_flight": len(slots), "frames_per_launch": B,

@@ -870,7 +870,8 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     a.bvh_depth = c->bvh_depth > 0 ? c->bvh_depth : 1;
     // the workgroups' LDS copy of the node table: all of it for small scenes, the breadth-first top for big ones
     static const int big_top_env = (int)r1_knob("R1_BIG_TOP", R1_BVH_TOP_NODES); // tuning experiments
-    a.bvh_lds_f4 = !(variant == 4 || variant == 5) ? 0u : (!big ? 4u * c->n_bvh_nodes : 4u * std::min<uint32_t>(c->n_bvh_nodes, (uint32_t)std::max(0, big_top_env)));
+    // (big scenes: at least node 0 — the walk's root step reads it from the LDS copy, whatever the tuning knob says)
+    a.bvh_lds_f4 = !(variant == 4 || variant == 5) ? 0u : (!big ? 4u * c->n_bvh_nodes : 4u * std::min<uint32_t>(c->n_bvh_nodes, (uint32_t)std::max(1, big_top_env)));
     const int occ_slot = variant + 8 * big + 16 * mode;
     if (c->occupancy[occ_slot] == 0)
         R1_HIP(r1_trace_occupancy(variant, big, mode,

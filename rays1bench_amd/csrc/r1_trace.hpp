@@ -67,6 +67,7 @@ typedef const f4 __attribute__((address_space(4))) *cf4_ptr;
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float f16 __attribute__((ext_vector_type(16)));
 typedef const f16 __attribute__((address_space(4))) *cf16_ptr;
+typedef uint32_t __attribute__((address_space(1))) r1_gu32; // a word of global memory (explicit: keeps rarely used stores / loads from becoming generic ones)
 
 // Correctly rounded sqrt / division.  NOT __fsqrt_rn/__fdiv_rn: without
 // OCML_BASIC_ROUNDED_OPERATIONS hipcc maps __fsqrt_rn to the approximate v_sqrt_f32.  Plain
@@ -818,7 +819,7 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
     if (root_leaf != 0u && cur == 0u) // (the first condition is wave-uniform)
     {
         const int k = root_leaf == 1u ? 1 : 0; // column of the OTHER child in the node's rows
-        const float *nf = (LN || top > 0u) ? (const float *)lnodes : (const float *)nodes; // node 0 (big scenes: in LDS with the top of the tree)
+        const float *nf = (const float *)lnodes; // node 0: always in the workgroup's LDS copy (big scenes keep the top of the tree there: at least node 0, r1_capi.cpp)
         const uint32_t leaf = __float_as_uint(nf[14 + (1 - k)]), other = __float_as_uint(nf[14 + k]);
         const uint32_t lp = (leaf >> COUNT_SHIFT) & 7u;
         if (STATS)
@@ -956,7 +957,11 @@ __device__ __forceinline__ void stack_push(uint32_t *stack, uint32_t *gstack, ui
     }
     if (LW < R1_STACK_WORDS && sp >= 3 * LW) // deep entries (rare): global workspace, [entry - 3 LW][global thread]
     {
-        gstack[(size_t)(sp - 3 * LW) * gstride + gtid] = idx;
+        // (the lane's part of the address is formed HERE: as a loop-invariant 64-bit value it is hoisted out of the tracing loop and spilled to scratch)
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));
+        const uint32_t g = (gtid & ~(uint32_t)(R1_BLOCK - 1)) | (uint32_t)t_; // (= gtid, rebuilt from the workgroup's wave-uniform part)
+        ((r1_gu32 *)gstack)[(uint32_t)(sp - 3 * LW) * gstride + g] = idx;
         return;
     }
     const int w = sp / 3, sh = (sp - 3 * w) * 10;
@@ -1228,9 +1233,12 @@ __device__ __forceinline__ bool shade_level(const R1TraceArgs &A, Path &p, const
             int top = p.sp;
             if (LW < R1_STACK_WORDS)
             {
+                int t2 = tid;
+                asm volatile("" : "+v"(t2)); // (as in stack_push)
+                const uint32_t g = (gtid & ~(uint32_t)(R1_BLOCK - 1)) | (uint32_t)t2;
                 for (int e = top - 1; e >= 3 * LW; --e) // the deep entries first (innermost attenuation first)
                 {
-                    const float4 sh = A.scene.shade[A.gstack[(size_t)(e - 3 * LW) * gstride + gtid]];
+                    const float4 sh = A.scene.shade[((const r1_gu32 *)A.gstack)[(uint32_t)(e - 3 * LW) * gstride + g]];
                     col = mk(sh.y * col.x, sh.z * col.y, sh.w * col.z);
                 }
                 top = top < 3 * LW ? top : 3 * LW;
@@ -1240,9 +1248,11 @@ __device__ __forceinline__ bool shade_level(const R1TraceArgs &A, Path &p, const
             // index is inside the table, r1_capi.cpp), and the slots above the top entry multiply by 1.0f, which changes
             // no bit: one round trip to the table per word instead of one per entry.
             int w = (top - 1) / 3, j = (top - 1) - 3 * w;
+            int t_ = tid;
+            asm volatile("" : "+v"(t_)); // (the lane's LDS offset is formed here: hoisted out of the tracing loop, tid * 4 was a spilled register reloaded at every path's end)
             for (; w >= 0; --w, j = 2)
             {
-                const uint32_t v = s_stack[w * R1_BLOCK + tid];
+                const uint32_t v = s_stack[w * R1_BLOCK + t_];
                 const float4 s2 = A.scene.shade[(v >> 20) & 0x3FFu], s1 = A.scene.shade[(v >> 10) & 0x3FFu], s0 = A.scene.shade[v & 0x3FFu];
                 const bool u2 = j >= 2, u1 = j >= 1;
                 col = mk((u2 ? s2.y : 1.0f) * col.x, (u2 ? s2.z : 1.0f) * col.y, (u2 ? s2.w : 1.0f) * col.z);
@@ -1307,7 +1317,13 @@ __device__ __forceinline__ void land_note(const R1TraceArgs &A, uint32_t *row, c
     if (at < R1_LAND_OWED)
         row[8u + at] = t;
     else if (at < R1_LAND_OWED + R1_LAND_OWED_SPILL)
-        A.land.owed_spill[(size_t)(blockIdx.x * (R1_BLOCK / 64) + (threadIdx.x >> 6)) * R1_LAND_OWED_SPILL + (at - R1_LAND_OWED)] = t;
+    {
+        // (32-bit index on a scalar base: as a 64-bit per-lane address the row's part of it is hoisted out of the tracing loop and spilled to scratch)
+        uint32_t tx = threadIdx.x;
+        asm volatile("" : "+v"(tx)); // (formed here, not hoisted)
+        const uint32_t wave = blockIdx.x * (R1_BLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(tx >> 6));
+        ((r1_gu32 *)A.land.owed_spill)[wave * R1_LAND_OWED_SPILL + (at - R1_LAND_OWED)] = t;
+    }
     else if (A.land.error)
         *A.land.error = 1u;
 }
@@ -1347,6 +1363,7 @@ __device__ __forceinline__ void land_chunk(const R1TraceArgs &A, uint32_t *row, 
 // One tile of the launch (t = frame * n_local_tiles + local tile) by ONE wave, lane l taking pixels l, l + 64, ...: false if a record
 // did not carry the launch's tag (nothing is accounted then; pixels written from such a pass are overwritten by the pass that
 // succeeds — the host sees the buffer only after the kernel).  Same arithmetic and order as r1_resolve_kernel = rayweek1.cpp:762-775.
+template <int LOADS /* records of one pixel a lane keeps in flight: 4 registers each */>
 __device__ __forceinline__ bool land_resolve_tile(const R1TraceArgs &A, const uint32_t t, const int lane)
 {
     const R1LandArgs &L = A.land;
@@ -1371,16 +1388,16 @@ __device__ __forceinline__ bool land_resolve_tile(const R1TraceArgs &A, const ui
         if (lx >= tw || ly >= th)
             continue; // void slots of an edge tile
         float cr = 0, cg = 0, cb = 0;
-        for (uint32_t s0 = 0; s0 < spp; s0 += R1_LAND_LOADS)
+        for (uint32_t s0 = 0; s0 < spp; s0 += LOADS)
         {
-            const uint32_t n = min((uint32_t)R1_LAND_LOADS, spp - s0); // (wave-uniform)
-            land_u4 v[R1_LAND_LOADS];
+            const uint32_t n = min((uint32_t)LOADS, spp - s0); // (wave-uniform)
+            land_u4 v[LOADS];
 #pragma unroll
-            for (uint32_t u = 0; u < R1_LAND_LOADS; ++u)
+            for (uint32_t u = 0; u < LOADS; ++u)
                 if (u < n)
                     v[u] = __builtin_amdgcn_raw_buffer_load_b128(rec, (int)(((s0 + u) * tile_px + pix) * 16u), 0, SC0);
 #pragma unroll
-            for (uint32_t u = 0; u < R1_LAND_LOADS; ++u)
+            for (uint32_t u = 0; u < LOADS; ++u)
                 if (u < n)
                 {
                     cr += __uint_as_float(v[u].x), cg += __uint_as_float(v[u].y), cb += __uint_as_float(v[u].z); // col += color(...) rayweek1.cpp:762
@@ -1418,6 +1435,7 @@ __device__ __forceinline__ bool land_resolve_tile(const R1TraceArgs &A, const ui
 }
 
 // A tracing wave has run out of work: what it still has to subtract, then the tiles it owes.
+template <int LOADS>
 __device__ __forceinline__ void land_exit(const R1TraceArgs &A, uint32_t *row, const int lane)
 {
     if (R1_LAND_EXP)
@@ -1439,11 +1457,14 @@ __device__ __forceinline__ void land_exit(const R1TraceArgs &A, uint32_t *row, c
             asm volatile("" : "+v"(t));
         }
         else
-            t = A.land.owed_spill[(size_t)(blockIdx.x * (R1_BLOCK / 64) + (threadIdx.x >> 6)) * R1_LAND_OWED_SPILL + (i - R1_LAND_OWED)];
+        {
+            const uint32_t wave = blockIdx.x * (R1_BLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            t = ((const r1_gu32 *)A.land.owed_spill)[wave * R1_LAND_OWED_SPILL + (i - R1_LAND_OWED)];
+        }
         t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
         // a record whose store is still on its way (the countdown is not ordered after the stores) shows an old tag: read again
         uint32_t tries = 0;
-        while (!land_resolve_tile(A, t, lane))
+        while (!land_resolve_tile<LOADS>(A, t, lane))
             if (++tries == R1_LAND_MAX_WAIT)
             {
                 if (lane == 0 && A.land.error)
@@ -1887,7 +1908,7 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
     }
 
     if (LAND)
-        land_exit(A, row, lane);
+        land_exit<(BIG && VARIANT == 4) ? 6 : R1_LAND_LOADS>(A, row, lane); // (the big-scene tree kernels are built for 64 registers)
 #undef row
     // ray count: wave reduction, one atomic per wave (rayweek1.cpp:809-813)
     if (!LAND)

@@ -336,6 +336,38 @@ def test_render_async_lands_the_frame_in_page_locked_host_memory(renderer):
         hf.close()
 
 
+def test_frames_in_flight_land_in_order_and_intact(renderer):
+    """Tiles summed inside the trace kernel: many frames in flight on several contexts, every one with its own seed
+    and size class, each landing in page-locked memory with no copy — every frame must equal the synchronous render of its seed
+    (records are handed from the tracing waves to the summing wave without a fence: a stale record would show here), launch after
+    launch through the same contexts (the two sets of cursors alternate), including ragged frames and frames of a single tile."""
+    rends = [r1.Renderer(0) for _ in range(6)]
+    try:
+        for (w, h, spp) in ((320, 200, 6), (77, 45, 3), (31, 17, 9), (640, 352, 2)):
+            sc = r1.create_large_scene(w, h)
+            renderer.set_scene(sc)
+            for r_ in rends:
+                r_.set_scene(sc)
+            hfs = [binding.HostFrames(w, h, 1) for _ in rends]
+            for rnd in range(5):
+                seeds = [1000 * rnd + 17 * k + w for k in range(len(rends))]
+                for hf in hfs:
+                    hf._all[:] = 0xCD
+                for r_, hf, sd in zip(rends, hfs, seeds):
+                    r_.render_async(mp(w, h, spp, sd), hf)
+                for r_ in rends:
+                    r_.sync()
+                for hf, sd in zip(hfs, seeds):
+                    img, rays, _ = renderer.render(mp(w, h, spp, sd))
+                    assert hf.rays(0) == rays, (w, h, spp, rnd, sd)
+                    assert hf.image(0).tobytes() == img.tobytes(), (w, h, spp, rnd, sd)
+            for hf in hfs:
+                hf.close()
+    finally:
+        for r_ in rends:
+            r_.close()
+
+
 def test_frame_batches_equal_single_frames(renderer):
     """Frame batches (r1_render_batch_async / r1_render_shard_device_batch): n frames in ONE launch, the persistent waves
     flowing from one frame into the next.  Every frame's pixels and ray count equal a synchronous r1_render of its seed —

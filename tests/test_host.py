@@ -4,6 +4,7 @@ include/rays1.h declares, the scene builders reproduce the reference's scenes bi
 common.h, and compute entry points fail loudly without a GPU."""
 import ctypes as C
 import os
+import sys
 import re
 
 import numpy as np
@@ -258,3 +259,30 @@ def test_record_sizes_keep_the_ray_counts_aligned():
         assert one.size == rec and int(one[rec - 8:].view(np.uint64)[0]) == 123456789012 and one[:block].tobytes() == blk.tobytes()
     bad = r1.make_params(0, 5, 1)
     assert binding.shard_record_bytes(bad) == 0 and binding.frame_record_bytes(bad) == 0
+
+
+def test_code_object_census_no_mfma_no_generic_loads_no_scratch():
+    """north_star: no MFMA on this path.  VERDICT r03 item 4: no generic (flat) loads — hipcc merges a select between an LDS and a
+    global address into one generic load — and no scratch in any product kernel: every r1_* kernel of librays1.so's gfx950 code
+    objects (one per translation unit) is read with llvm-readelf / llvm-objdump (tools/kernel_meta.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_meta
+    lib = os.path.join(ROOT, "rays1bench_amd", "lib", "librays1.so")
+    if not (os.path.exists(lib) and os.path.exists(kernel_meta.LLVM + "/llvm-objdump")):
+        pytest.skip("no library / no LLVM tools")
+    k = kernel_meta.collect(lib)
+    traces = [n for n in k if "r1_trace_kernel" in n]
+    assert len(traces) == 19 and len(k) >= 25  # the trace kernel's instances + wavefront / resolve / assemble / helpers
+    for name, m in k.items():
+        assert m["v_mfma"] == 0, name
+        assert m["flat_load"] == 0, name
+        diagnostic = re.search(r"r1_trace_kernelILi\d+ELb1E", name) is not None  # r1_trace_kernel<VARIANT, STATS = true, ...>
+        if not diagnostic:  # (the diagnostic builds keep 18 64-bit counters per lane and write a per-wave log through a pointer read from memory)
+            assert m["flat_store"] == 0, name
+            assert int(m["scratch"]) == 0 and m["scratch_insts"] == 0 and int(m["vgpr_spill"]) == 0, (name, m)
+    # register budgets the launch geometry relies on (DESIGN.md §4.4): 7 waves per SIMD for the small-scene throughput tree kernels, 8 for the big-scene ones
+    for name in traces:
+        if "ILi4ELb0ELb0ELi0E" in name or "ILi4ELb0ELb0ELi3E" in name:
+            assert int(k[name]["vgpr"]) <= 72, name
+        if "ILi4ELb0ELb1ELi0E" in name or "ILi4ELb0ELb1ELi3E" in name:
+            assert int(k[name]["vgpr"]) <= 64 and int(k[name]["sgpr"]) <= 96, name

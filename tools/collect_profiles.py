@@ -78,6 +78,9 @@ fl, wl, fs, ws = means("pmc_FETCH_SIZE", lat), means("pmc_WRITE_SIZE", lat), mea
 hb = lambda a, b: (2 * a["FETCH_SIZE"][0] + b["WRITE_SIZE"][0]) * 1024
 traffic = {"workload": "large 1200x800x10", "kernel": "r1_trace_kernel<4,false,false,0> (box tree, frames in flight: the kernel bench.py times)",
            "kernel_variant": 4,
+           # the build the counters belong to: bench.py quotes them only while it runs the same library.  The
+           # profile run writes the hash next to its outputs (tools/profile_round.sh: lib_sha16.txt)
+           "lib_sha16": (open(f"{out}/lib_sha16.txt").read().strip() if os.path.exists(f"{out}/lib_sha16.txt") else None),
            "source": f"profiles/{tag}/pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py --no-cpu-baseline "
                      f"--steps 3 --warmup 1 --inflight 1; mean over {f['FETCH_SIZE'][1]} dispatches)",
            "FETCH_SIZE_KB": f["FETCH_SIZE"][0], "WRITE_SIZE_KB": w["WRITE_SIZE"][0],

@@ -10,6 +10,7 @@ TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT && mkdir -p $OUT
+python3 -c "import hashlib,sys;print(hashlib.sha256(open(sys.argv[1],'rb').read()).hexdigest()[:16])" $R/rays1bench_amd/lib/librays1.so > $OUT/lib_sha16.txt
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $OUT/k16 -o k16 --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $OUT/k16.log 2>&1 || echo "k16 failed"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $OUT/k20 -o k20 --output-format csv -- python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 > $OUT/k20.log 2>&1 || echo "k20 failed"
