@@ -335,6 +335,22 @@ int r1_multi_render_async(r1_multi *m, const r1_params *params, void *host_frame
  * r1_render_batch_async): host_frames receives n_frames frame records. */
 int r1_multi_render_batch_async(r1_multi *m, const r1_params *params, int32_t n_frames, uint32_t seed_stride, void *host_frames);
 int r1_multi_sync(r1_multi *m);
+/* Where everything lies in the buffers of an n_devices-device frame or batch of n_frames frames: pure arithmetic (no device, no
+ * r1_multi object), the very function the r1_multi_* entry points size and address their buffers with; so the layout of an N-GPU
+ * run can be checked on a machine with one GPU or none (the join it describes: rayweek1.cpp:869-877, :809-813). */
+typedef struct r1_multi_layout_info
+{
+    size_t block_bytes;        /* a device's dense tile block of ONE frame (r1_shard_block_bytes) */
+    size_t record_bytes;       /* the block padded to 8 bytes + the device's uint64 ray count (r1_shard_record_bytes) */
+    size_t count_offset;       /* the count's offset in a record */
+    size_t send_bytes;         /* what a device hands to the all-gather: its n_frames records */
+    size_t gathered_bytes;     /* what it receives: [device][frame][record] */
+    size_t frame_record_bytes; /* an assembled frame: row-major image padded to 8 bytes + the frame's uint64 count (r1_frame_record_bytes) */
+    size_t frame_count_offset;
+    size_t host_bytes;         /* the one copy to the host: n_frames frame records */
+    size_t counts_pitch;       /* distance between two devices' records in the gathered buffer */
+} r1_multi_layout_info;
+int r1_multi_layout(const r1_params *params, int32_t n_devices, int32_t n_frames, r1_multi_layout_info *out);
 /* Facts for reports: device count, RCCL version code (ncclGetVersion), launch info of the first device. */
 int r1_multi_info(r1_multi *m, int32_t *n_devices, int32_t *rccl_version, r1_launch_info *first_device);
 

@@ -62,6 +62,11 @@ class Params(C.Structure):
     ]
 
 
+class MultiLayout(C.Structure):
+    _fields_ = [(k, C.c_size_t) for k in ("block_bytes", "record_bytes", "count_offset", "send_bytes", "gathered_bytes", "frame_record_bytes",
+                                          "frame_count_offset", "host_bytes", "counts_pitch")]
+
+
 class LaunchInfo(C.Structure):
     _fields_ = [("compute_units", C.c_int32), ("blocks", C.c_int32), ("threads_per_block", C.c_int32),
                 ("spheres_active", C.c_int32), ("spheres_padded", C.c_int32), ("groups", C.c_int32), ("samples", C.c_uint64),
@@ -132,6 +137,7 @@ SYMBOLS = [
     ("r1_multi_render_async", C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p]),
     ("r1_multi_render_batch_async", C.c_int, [C.c_void_p, C.POINTER(Params), C.c_int32, C.c_uint32, C.c_void_p]),
     ("r1_multi_sync", C.c_int, [C.c_void_p]),
+    ("r1_multi_layout", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ("r1_multi_info", C.c_int, [C.c_void_p, _i32p, _i32p, C.POINTER(LaunchInfo)]),
     ("r1_assemble_device", C.c_int, [_ctx, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p]),
     ("r1_assemble_device_strided", C.c_int, [_ctx, C.POINTER(Params), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
@@ -500,6 +506,13 @@ def tile_count(params):
     a, b = C.c_int32(), C.c_int32()
     _check(lib().r1_tile_count(C.byref(params), C.byref(a), C.byref(b)))
     return int(a.value), int(b.value)
+
+
+def multi_layout(params, n_devices, n_frames=1):
+    """r1_multi_layout: the buffer layout of an n_devices-device frame / batch (pure arithmetic, no device needed)."""
+    out = MultiLayout()
+    _check(lib().r1_multi_layout(C.byref(params), n_devices, n_frames, C.byref(out)))
+    return {k: int(getattr(out, k)) for k, _ in MultiLayout._fields_}
 
 
 def bvh_describe(cscene, leaf_max=0):

@@ -786,7 +786,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     }
     // tiles resolved inside the trace kernel: the product kernels' launches; the diagnostic builds, the reference-form
     // sweep, the wavefront variant and PIXEL mode keep the round-3 form (records + r1_resolve_kernel, or no records at all)
-    const bool land = R1_LAND && (variant == 2 || variant == 4) && mode == 0 && c->total_samples > 0;
+    const bool land = (variant == 2 || variant == 4) && R1_LAND_MODE(mode) && c->total_samples > 0;
     if (!pixel_mode)
     {
         const size_t want = (size_t)(c->total_samples ? c->total_samples : 1) * 16;
@@ -941,7 +941,9 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
         a.chunk_max = (uint32_t)cm;
         a.chunk_min = 8;
     }
-    if (mode == 1)
+    if (mode == 1 && land)
+        a.chunk_max = a.chunk_min = 64u; // (the XCDs' cursors hand out the wave-fulls: eight lines instead of one, no sub-queues)
+    else if (mode == 1)
     {
         static const int nq_env = (int)r1_knob("R1_NQ", 0), ch_env = (int)r1_knob("R1_CHUNK", 0);
         long long nq = nq_env > 0 ? nq_env : R1_SUBQUEUES;

@@ -53,6 +53,10 @@
 #ifndef R1_LAND
 #define R1_LAND 1
 #endif
+#ifndef R1_LAND_SYNC
+#define R1_LAND_SYNC 0 // 1: the synchronous frame's kernels (MODE 1) too — measured and not adopted: 1.276 against 1.077 ms on the device (the tiles a wave owes are summed at ITS exit, i.e. at the end of the frame's critical path; the resolve launch sums all 950 in 26 us with the whole chip), profiles/r04/land_sync_frame.txt
+#endif
+#define R1_LAND_MODE(mode) (R1_LAND && ((mode) == 0 || (mode) == 3 || (R1_LAND_SYNC && (mode) == 1)))
 #define R1_LAND_CNT_STRIDE 32u  // words between two tiles' countdowns: every countdown on its own 128-byte line (an atomic on ONE line sustains ~88 M/s on this chip,
                                // tools/ubench_atomic.hip; the ~40 tiles a synchronous frame's waves work on at a time shared two lines at first: 3.8 ms per frame instead of 1.1)
 #define R1_LAND_MAX_WAIT (1u << 16) // passes over a claimed tile that still find a record of an earlier launch before the wave gives up and flags the launch

@@ -267,6 +267,37 @@ static int multi_buffers(r1_multi *m, const size_t record, const size_t rgb_byte
     return R1_OK;
 }
 
+// Where everything lies in the buffers of an N-device frame (or batch of frames) — pure arithmetic, no device: what every r1_multi_*
+// entry point below sizes and addresses its buffers with, exported so that the layout can be checked for any N on a machine with one GPU
+// or none (tests/test_multirank_cpu.py compares it with the host mirror of the rank path, rays1bench_amd/sharding.py).
+extern "C" int r1_multi_layout(const r1_params *params, int32_t n_devices, int32_t n_frames, r1_multi_layout_info *out)
+{
+    if (!params || !out || n_devices < 1 || n_frames < 1)
+    {
+        r1_set_error("r1_multi_layout: bad argument");
+        return R1_EINVAL;
+    }
+    r1_params p = *params;
+    p.shard = 0, p.num_shards = n_devices;
+    const size_t block = r1_shard_block_bytes(&p), record = r1_shard_record_bytes(&p), frame = r1_frame_record_bytes(&p);
+    if (block == 0 || record == 0 || frame == 0)
+        return R1_EINVAL;
+    memset(out, 0, sizeof(*out));
+    out->block_bytes = block;                                  // a device's dense tile block of ONE frame
+    out->record_bytes = record;                                // block padded to 8 bytes + the device's uint64 ray count
+    out->count_offset = record - 8;                            // ... the count's place in a record
+    out->send_bytes = record * (size_t)n_frames;               // what a device hands to the all-gather: its n_frames records
+    out->gathered_bytes = out->send_bytes * (size_t)n_devices; // what it receives: [device][frame][record]
+    out->frame_record_bytes = frame;                           // an assembled frame: row-major image padded to 8 bytes + the frame's uint64 count
+    out->frame_count_offset = frame - 8;
+    out->host_bytes = frame * (size_t)n_frames;                // the one copy to the host
+    out->counts_pitch = record * (size_t)n_frames;             // single frames: the N counts are a strided 8-byte column of the gathered buffer
+    return R1_OK;
+}
+
+// record of device d, frame f in a gathered buffer
+static inline size_t gathered_at(const r1_multi_layout_info &L, int32_t n_frames, int d, int f) { return ((size_t)d * n_frames + f) * L.record_bytes; }
+
 extern "C" int r1_multi_render(r1_multi *m, const r1_params *params, uint8_t *rgb_out, uint64_t *num_rays_out, double *device_seconds_out)
 {
     if (!m || !params || !rgb_out)
@@ -276,11 +307,11 @@ extern "C" int r1_multi_render(r1_multi *m, const r1_params *params, uint8_t *rg
     }
     r1_params p = *params;
     p.shard = 0, p.num_shards = m->n;
-    const size_t block = r1_shard_block_bytes(&p);
-    if (block == 0)
+    r1_multi_layout_info L;
+    if (r1_multi_layout(&p, m->n, 1, &L) != R1_OK)
         return R1_EINVAL;
-    const size_t record = r1_shard_record_bytes(&p); // block, padded to 8 bytes, + the shard's uint64 ray count: pixels and counts travel in one collective
-    const size_t trailer = record - 8;
+    const size_t record = L.record_bytes; // block, padded to 8 bytes, + the shard's uint64 ray count: pixels and counts travel in one collective
+    const size_t trailer = L.count_offset;
     const size_t rgb_bytes = (size_t)p.width * p.height * 3;
     {
         const int rc_buf = multi_buffers(m, record, rgb_bytes);
@@ -346,7 +377,7 @@ extern "C" int r1_multi_render(r1_multi *m, const r1_params *params, uint8_t *rg
         {
             he = hipMemcpyAsync(rgb_out, m->d_rgb, rgb_bytes, hipMemcpyDeviceToHost, m->stream[0]);
             if (he == hipSuccess)
-                he = hipMemcpy2DAsync(counts.data(), 8, (char *)m->d_gathered[0] + trailer, record, 8, (size_t)m->n, hipMemcpyDeviceToHost, m->stream[0]);
+                he = hipMemcpy2DAsync(counts.data(), 8, (char *)m->d_gathered[0] + gathered_at(L, 1, 0, 0) + trailer, L.counts_pitch, 8, (size_t)m->n, hipMemcpyDeviceToHost, m->stream[0]);
             if (he != hipSuccess)
             {
                 r1_set_error("r1_multi_render: copy to the host failed: %s", hipGetErrorString(he));
@@ -405,11 +436,12 @@ extern "C" int r1_multi_render_batch_async(r1_multi *m, const r1_params *params,
     }
     r1_params p = *params;
     p.shard = 0, p.num_shards = m->n;
-    const size_t record = r1_shard_record_bytes(&p), frame = r1_frame_record_bytes(&p);
-    if (record == 0 || frame == 0)
+    r1_multi_layout_info L;
+    if (r1_multi_layout(&p, m->n, n_frames, &L) != R1_OK)
         return R1_EINVAL;
+    const size_t record = L.record_bytes, frame = L.frame_record_bytes;
     {
-        const int rc_buf = multi_buffers(m, record * (size_t)n_frames, frame * (size_t)n_frames);
+        const int rc_buf = multi_buffers(m, L.send_bytes, L.host_bytes);
         if (rc_buf != R1_OK)
             return rc_buf;
     }

@@ -1273,19 +1273,20 @@ __device__ __forceinline__ bool shade_level(const R1TraceArgs &A, Path &p, const
 // What makes it cheap is that a tile never leaves its XCD.  The eight XCDs' L2s are not coherent with each other: records traced on
 // one XCD and summed on another must be written through to memory (sc1 stores: +7 % on the tracing loop, measured) and waited for
 // by workgroups that do nothing else (+14 %): profiles/r04/land_cross_xcd_cost_breakdown.txt, the first form of this code.  So:
-//   * a tile belongs to the XCD that CLAIMS it: every XCD has a cursor {tile, next sample slot of that tile} its waves take their chunks
-//     from; the wave that takes a tile's last chunk (or finds no tile installed yet) claims the launch's next unclaimed tile for its
+//   * a tile belongs to the XCD that CLAIMS it: every XCD has a cursor {tile (or group of 8 tiles), next sample slot} its waves take their
+//     chunks from; the wave that takes the last chunk (or finds nothing installed yet) claims the launch's next unclaimed tile(s) for its
 //     XCD and installs it; waves that meet a used-up tile meanwhile wait for that (microseconds).  Nothing
 //     is assumed about which XCD a workgroup runs on — the dispatcher deals them round-robin, starting wherever the last launch
 //     stopped — and XCDs that run faster simply claim more tiles;
-//   * the waves of an XCD store the records with plain stores and count the samples they finish per tile — in two scalar registers for
-//     the tiles of the wave's current and previous chunk — and subtract the count from the tile's countdown when the wave moves on to
-//     another tile (an atomic per finished sample group and iteration cost 7 %: the vector-memory counter of this chip is in order,
-//     so every iteration's first load waited for the atomic in front of it);
-//   * the subtraction that brings a countdown to zero is unique: that wave OWES the tile.  It notes it (a few words of LDS per wave)
-//     and, when it has run out of work, sums its tiles before it exits — their records sit in this XCD's L2 or in memory, nowhere
-//     else — adds each tile's rays to the frame's count and re-arms the countdown for the next launch.  The wave that takes the
-//     frame's last tile off publishes the ray count.  (A wave whose notes are full takes no more samples: it ends early and pays.)
+//   * the waves of an XCD store the records with plain stores and count the samples they finish per tile — in LDS, for the tiles of the
+//     wave's current and previous chunk — and subtract the count from the tile's countdown when the wave moves on to another tile: one
+//     fire-and-forget atomic per chunk (an atomic per finished sample group and iteration cost 7 %: the vector-memory counter of this
+//     chip is in order, so every iteration's first load waited for the memory-side atomic in front of it; a returning one per chunk 3 %);
+//   * a wave that has run out of work looks at the tiles it ever took a chunk from (a short list in its LDS row): a countdown at zero is
+//     swapped for a mark, and the wave that wins the swap sums the tile — its records sit in this XCD's L2 or in memory, nowhere else —
+//     adds the tile's rays to the frame's count and re-arms the countdown for the next launch.  Of the waves that worked on a tile the
+//     last to get there finds it complete, so every tile is summed.  The wave that takes the frame's last tile off publishes the ray
+//     count.  (A wave whose list is full takes no more samples: it ends early.)
 //   * every record carries the launch's tag in its ray-count word: a countdown is not ordered after the stores it counts, so a wave
 //     that finds a record of an earlier launch in a tile it owes simply reads the tile again (past the vector L1: sc0 loads).
 // Per launch, behind the queue pointer (one of two sets, zeroed by the launch after): line x = XCD x's cursor (uint64); line 16 = the
@@ -1295,7 +1296,7 @@ __device__ __forceinline__ bool shade_level(const R1TraceArgs &A, Path &p, const
 #endif
 #define R1_LAND_OWED 24u        // tiles a wave can owe: words of LDS per wave ...
 #define R1_LAND_OWED_SPILL 136u // ... and of its row in the spill area behind them
-#define R1_LAND_LOADS 10     // records of one pixel a lane keeps in flight while it sums a tile
+#define R1_LAND_LOADS 8      // records of one pixel a lane keeps in flight while it sums a tile (4 registers each; 10 spill in the 72-register builds)
 #define R1_LAND_MAX_XCD 8u
 
 __device__ __forceinline__ uint32_t xcc_id() { return (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u; } // HW_REG_XCC_ID[3:0]
@@ -1305,15 +1306,16 @@ __device__ __forceinline__ uint32_t xcc_id() { return (uint32_t)__builtin_amdgcn
 // vector register from the loop (five such values: +6.5 % per frame, profiles/r04/land_xcd_local_steps.txt).
 //   [0] t0, [1] n0: tile of the wave's current chunk, samples of it the wave has finished since it last subtracted
 //   [2] t1, [3] n1: the same for the previous chunk's tile
-//   [4] owed: tiles this wave brought to zero and has not summed yet; [8 ...]: their indices (the first R1_LAND_OWED of them)
+//   [4] touched: tiles this wave has taken chunks from; [8 ...]: their indices (the first R1_LAND_OWED of them)
 #define R1_LAND_ROW 32u
+#define R1_LAND_CLAIMED 0xFFFFFFFFu
 
-// tile t has been brought to zero by this lane's subtraction: the wave owes it
+// the wave takes a chunk from tile t for the first time (or again): t goes on the list of tiles it looks at before it exits.  ONE lane.
 __device__ __forceinline__ void land_note(const R1TraceArgs &A, uint32_t *row, const uint32_t t)
 {
-    const uint32_t at = atomicAdd(&row[4], 1u); // (LDS)
-    // (past R1_LAND_OWED the wave's row of the spill area.  A wave stops taking samples at R1_LAND_OWED - 3 owed tiles, and what it
-    //  then still finishes — at most the 64 paths and 64 spare samples it holds — cannot bring more than that many tiles to zero)
+    const uint32_t at = row[4];
+    row[4] = at + 1u;
+    // (past R1_LAND_OWED the wave's row of the spill area; a wave whose list is nearly full takes no more chunks, see the fetch)
     if (at < R1_LAND_OWED)
         row[8u + at] = t;
     else if (at < R1_LAND_OWED + R1_LAND_OWED_SPILL)
@@ -1328,13 +1330,13 @@ __device__ __forceinline__ void land_note(const R1TraceArgs &A, uint32_t *row, c
         *A.land.error = 1u;
 }
 
-// subtract n finished samples from tile t's countdown; whoever reaches zero owes the tile.  ONE lane.
-__device__ __forceinline__ void land_flush(const R1TraceArgs &A, uint32_t *row, const uint32_t t, const uint32_t n)
+// subtract n finished samples from tile t's countdown: fire and forget (a RETURNING atomic here — "who reaches zero owes the tile" —
+// stalled the wave for a memory-side round trip at every chunk: +3 % per frame).  Who sums the tile is settled when waves exit.
+__device__ __forceinline__ void land_flush(const R1TraceArgs &A, const uint32_t t, const uint32_t n)
 {
     if (n == 0u || R1_LAND_EXP >= 2)
         return;
-    if (__hip_atomic_fetch_sub(A.land_cnt + t * R1_LAND_CNT_STRIDE, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n)
-        land_note(A, row, t);
+    (void)__hip_atomic_fetch_sub(A.land_cnt + t * R1_LAND_CNT_STRIDE, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // this lane has just stored the record of sample slot k: one more finished sample of its tile.  Per lane, no wave-uniform state.
@@ -1346,7 +1348,7 @@ __device__ __forceinline__ void land_count(const R1TraceArgs &A, uint32_t *row, 
     else if (j == row[2])
         atomicAdd(&row[3], 1u);
     else
-        land_flush(A, row, j, 1u); // (rare: a path that outlived two chunks)
+        land_flush(A, j, 1u); // (rare: a path that outlived two chunks; its tile is on the wave's list since the chunk was taken)
 }
 
 // the wave's next chunk comes from tile t.  ONE lane.
@@ -1355,9 +1357,10 @@ __device__ __forceinline__ void land_chunk(const R1TraceArgs &A, uint32_t *row, 
     const uint32_t t0 = row[0];
     if (t == t0)
         return;
-    land_flush(A, row, row[2], row[3]);
+    land_flush(A, row[2], row[3]);
     row[2] = t0, row[3] = row[1];
     row[0] = t, row[1] = 0u;
+    land_note(A, row, t);
 }
 
 // One tile of the launch (t = frame * n_local_tiles + local tile) by ONE wave, lane l taking pixels l, l + 64, ...: false if a record
@@ -1434,43 +1437,68 @@ __device__ __forceinline__ bool land_resolve_tile(const R1TraceArgs &A, const ui
     return true;
 }
 
-// A tracing wave has run out of work: what it still has to subtract, then the tiles it owes.
+// A tracing wave has run out of work: it subtracts what it still holds, then looks at every tile it ever took a chunk from.  A countdown
+// at zero means every sample of the tile has been counted; the wave that swaps the zero for the CLAIMED mark sums the tile.  Every tile
+// finds its wave: of the waves that worked on a tile, the last to get here has seen all the others subtract (they waited for their
+// atomics before they looked), so it reads zero unless another wave already has the tile.
 template <int LOADS>
 __device__ __forceinline__ void land_exit(const R1TraceArgs &A, uint32_t *row, const int lane)
 {
     if (R1_LAND_EXP)
         return;
+#ifdef R1_LAND_EXIT_PRIO
+    __builtin_amdgcn_s_setprio(R1_LAND_EXIT_PRIO); // (a wave that sums tiles holds its workgroup's slot: let it finish first)
+#endif
     if (lane == 0)
     {
-        land_flush(A, row, row[2], row[3]);
-        land_flush(A, row, row[0], row[1]);
+        land_flush(A, row[2], row[3]);
+        land_flush(A, row[0], row[1]);
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): (the spill area's stores)
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): this wave's record stores, subtractions and spilled list entries have been performed
     __builtin_amdgcn_wave_barrier();
-    const uint32_t owed = min((uint32_t)__builtin_amdgcn_readfirstlane((int)row[4]), R1_LAND_OWED + R1_LAND_OWED_SPILL);
-    for (uint32_t i = 0; i < owed; ++i)
+    const uint32_t touched = min((uint32_t)__builtin_amdgcn_readfirstlane((int)row[4]), R1_LAND_OWED + R1_LAND_OWED_SPILL);
+    for (uint32_t base = 0; base < touched; base += 64u) // (wave-uniform; one trip unless the list spilled)
     {
-        uint32_t t; // (two loads kept apart: a select between an LDS and a global address becomes a generic load)
-        if (i < R1_LAND_OWED)
+        const uint32_t i = base + (uint32_t)lane;
+        uint32_t t = 0u, c = 1u;
+        if (i < touched)
         {
-            t = row[8u + i];
-            asm volatile("" : "+v"(t));
-        }
-        else
-        {
-            const uint32_t wave = blockIdx.x * (R1_BLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-            t = ((const r1_gu32 *)A.land.owed_spill)[wave * R1_LAND_OWED_SPILL + (i - R1_LAND_OWED)];
-        }
-        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-        // a record whose store is still on its way (the countdown is not ordered after the stores) shows an old tag: read again
-        uint32_t tries = 0;
-        while (!land_resolve_tile<LOADS>(A, t, lane))
-            if (++tries == R1_LAND_MAX_WAIT)
+            if (i < R1_LAND_OWED)
             {
-                if (lane == 0 && A.land.error)
-                    *A.land.error = 1u; // never in a correct run; the host reports the launch as failed
-                break;
+                t = row[8u + i];
+                asm volatile("" : "+v"(t)); // (two loads kept apart: a select between an LDS and a global address becomes a generic load)
             }
+            else
+            {
+                const uint32_t wave = blockIdx.x * (R1_BLOCK / 64) + (threadIdx.x >> 6);
+                t = ((const r1_gu32 *)A.land.owed_spill)[wave * R1_LAND_OWED_SPILL + (i - R1_LAND_OWED)];
+            }
+            // (device scope: the countdowns are only ever touched by atomics, which are performed behind the L2s)
+            c = __hip_atomic_load(A.land_cnt + t * R1_LAND_CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c == 0u) // every lane that reads zero tries for its tile; one wave of the XCD wins it
+            {
+                uint32_t seen = 0u;
+                if (!__hip_atomic_compare_exchange_strong(A.land_cnt + t * R1_LAND_CNT_STRIDE, &seen, R1_LAND_CLAIMED, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT))
+                    c = 1u;
+            }
+        }
+        unsigned long long mine = __ballot(c == 0u);
+        while (mine)
+        {
+            const int b = __ffsll((long long)mine) - 1;
+            mine &= mine - 1ull;
+            const uint32_t tt = (uint32_t)__builtin_amdgcn_readlane((int)t, b);
+            // a record whose store is still on its way (the countdown is not ordered after the stores) shows an old tag: read again
+            uint32_t tries = 0;
+            while (!land_resolve_tile<LOADS>(A, tt, lane))
+                if (++tries == R1_LAND_MAX_WAIT)
+                {
+                    if (lane == 0 && A.land.error)
+                        *A.land.error = 1u; // never in a correct run; the host reports the launch as failed
+                    break;
+                }
+        }
     }
 }
 
@@ -1511,7 +1539,7 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
     // tiles resolved inside the kernel: the throughput builds of the product kernels (frames in flight, MODE 0 / 3); a
     // launch through them is a landing launch (r1_launch_trace checks).  The synchronous frame keeps the resolve launch: its tiles would
     // have to be dealt to the XCDs dynamically (the XCDs of one chip run this kernel up to 20 % apart), see DESIGN.md §4.10.
-    constexpr bool LAND = R1_LAND && !STATS && (MODE == 0 || MODE == 3) && VARIANT != 1;
+    constexpr bool LAND = R1_LAND_MODE(MODE) && !STATS && VARIANT != 1;
     const uint32_t tb = blockIdx.x, n_tb = gridDim.x;
     // LAND: this workgroup's XCD (HW_REG_XCC_ID), the tiles of the launch
     const uint32_t xcd = LAND ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(xcc_id() & 7u)) : 0u;
@@ -1619,6 +1647,9 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
     uint32_t q_remaining = q_total;
     const uint32_t n_waves2 = 2u * n_tb * (R1_BLOCK / 64);
     uint32_t *const q_head = LAND ? A.queue + 32u * xcd : A.queue;
+    // tiles an XCD claims at a time.  A synchronous frame has the whole chip on 64-sample chunks: an XCD is through a tile in ~8 us, and
+    // the ~5 us its cursor is closed while the next claim is installed would be most of that (1.65 ms per frame with one tile per claim)
+    constexpr uint32_t LAND_GROUP = LAT ? 8u : 1u;
     __shared__ uint32_t s_land[LAND ? (R1_BLOCK / 64) * R1_LAND_ROW : 1];
 #define row (s_land + (LAND ? (threadIdx.x >> 6) * R1_LAND_ROW : 0u)) /* this wave's row (see land_count); recomputed where it is used: one register less around the loop */
     if (LAND && lane < 8)
@@ -1682,27 +1713,35 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
                         unsigned long long old = 0;
                         if (lane == 0)
                             old = __hip_atomic_fetch_add((unsigned long long *)q_head, (unsigned long long)want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(old >> 32)); // tile + 1; 0: none installed yet; ~0: none left
-                        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)old);          // slots of the tile handed out before this call
+                        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(old >> 32)); // group + 1; 0: none installed yet; ~0: none left
+                        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)old);          // slots of the group handed out before this call
                         if (hi == 0xFFFFFFFFu)
                             break;
-                        const bool have = hi != 0u && lo < A.full;
-                        const bool advance = (hi == 0u && lo == 0u) || (have && lo + want >= A.full); // exactly one wave per installed tile (and per XCD at the start)
+                        // a group = LAND_GROUP consecutive tiles claimed at once (the last one of a launch may be shorter)
+                        const uint32_t g0 = (hi - 1u) * LAND_GROUP;
+                        const uint32_t gs = hi != 0u ? min(LAND_GROUP, land_tiles - g0) * A.full : 0u;
+                        const bool have = hi != 0u && lo < gs;
+                        const bool advance = (hi == 0u && lo == 0u) || (have && lo + want >= gs); // exactly one wave per installed group (and per XCD at the start)
                         if (advance && lane == 0)
                         {
                             const uint32_t g = __hip_atomic_fetch_add(A.queue + 32u * 16u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             unsigned long long nv = 0xFFFFFFFFull << 32;
-                            if (g < land_tiles)
+                            if (g * LAND_GROUP < land_tiles)
                                 nv = (unsigned long long)(g + 1u) << 32;
                             (void)__hip_atomic_exchange((unsigned long long *)q_head, nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                         if (have)
                         {
-                            base = (hi - 1u) * A.full + lo;
-                            want = min(want, A.full - lo);
-                            q_remaining = (land_tiles - min(land_tiles, hi)) * A.full; // (the tiles behind this one: what the next call is guided by)
+                            base = g0 * A.full + lo;
+                            want = min(want, gs - lo);
+                            q_remaining = (land_tiles - min(land_tiles, g0 + LAND_GROUP)) * A.full; // (the tiles behind this group: what the next call is guided by)
+                            const uint32_t tl = fastdiv(lo, A.div_full); // the chunk's (first) tile within the group
                             if (lane == 0)
-                                land_chunk(A, row, hi - 1u);
+                            {
+                                land_chunk(A, row, g0 + tl);
+                                if (lo - tl * A.full + want > A.full) // (it runs on into the next tile: a chunk is at most one tile long)
+                                    land_chunk(A, row, g0 + tl + 1u);
+                            }
                             break;
                         }
                         if (advance)

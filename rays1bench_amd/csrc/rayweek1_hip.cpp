@@ -483,7 +483,19 @@ int main(int argc, const char *argv[])
         g_ctx.push_back(c);
     }
 
-    Pix *pixels = new Pix[(size_t)g_screen_w * g_screen_h];
+    // The pixel buffer benchmark() fills (rayweek1.cpp:961 allocates it with new[]).  With the HIP backend it is page-locked memory
+    // (r1_host_alloc): the trace launch then stores every finished tile straight into it and r1_render copies nothing
+    // (include/rays1.h; any other memory works too and costs one copy of the image per frame).
+    Pix *pixels = nullptr;
+    bool pixels_pinned = false;
+    if (g_backend == 0)
+    {
+        void *mem = nullptr;
+        if (r1_host_alloc((size_t)g_screen_w * g_screen_h * sizeof(Pix), &mem) == R1_OK)
+            pixels = (Pix *)mem, pixels_pinned = true;
+    }
+    if (!pixels)
+        pixels = new Pix[(size_t)g_screen_w * g_screen_h];
     memset(pixels, 0, (size_t)g_screen_w * g_screen_h * sizeof(pixels[0]));
 
     const char *version = g_backend == 0 ? "hip" : (g_backend == 12 ? "cpu-step12" : "cpu-step1");
@@ -511,7 +523,10 @@ int main(int argc, const char *argv[])
         rc_pipe |= pipelined("large", R1_SCENE_LARGE, g_pipeline);
     }
 
-    delete[] pixels;
+    if (pixels_pinned)
+        r1_host_free(pixels);
+    else
+        delete[] pixels;
     for (r1_context *c : g_ctx)
         r1_destroy(c);
     r1_multi_destroy(g_multi);

@@ -554,7 +554,7 @@ def test_bench_two_ranks_rehearsal_gathers_the_unsharded_frame():
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     line = json.loads(out.stdout.decode().strip().splitlines()[-1])
     assert line["check"] is True and line["n_gpus"] == 2 and line["scaling"] == "strong"
-    assert "to page-locked HOST memory" in line["config"]["value_mode"]
+    assert "in page-locked HOST memory" in line["config"]["value_mode"]
     assert "cpu_baseline" not in line and line["roofline"]["bound"] == "valu" and 0 < line["roofline"]["frac"] <= 1
     assert line["value_device_resident"]["value"] > 0
 

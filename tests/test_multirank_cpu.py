@@ -112,3 +112,35 @@ def test_sharding_helpers_match_c_abi():
         img = rng.integers(1, 255, (h, w, 3), dtype=np.uint8)
         blocks = np.concatenate([sharding.pack_block(img, s, n) for s in range(n)])
         assert sharding.assemble(blocks, w, h, n).tobytes() == img.tobytes()
+
+
+@pytest.mark.parametrize("n", [2, 3, 8])
+@pytest.mark.parametrize("w,h,tw,th,frames", [(1200, 800, 32, 32, 1), (300, 200, 32, 32, 4), (77, 45, 5, 7, 2), (1920, 1080, 32, 32, 8)])
+def test_in_process_multi_gpu_layout_equals_the_rank_path_mirror(n, w, h, tw, th, frames):
+    """r1_multi_layout is the arithmetic csrc/r1_multi.cpp sizes and addresses its buffers with (records, the gathered
+    [device][frame][record] buffer, the strided column of counts, the frame records that go to the host).  No device is involved, so
+    N = 2, 3, 8 are checked here against the host mirror of the rank path (sharding.py) — the N > 1 run itself is the driver's."""
+    from rays1bench_amd import binding
+    p = r1.make_params(w, h, 4, 1, tile_w=tw, tile_h=th)
+    L = binding.multi_layout(p, n, frames)
+    assert L["block_bytes"] == sharding.block_bytes(w, h, n, tw, th)
+    assert L["record_bytes"] == sharding.record_bytes(w, h, n, tw, th) and L["record_bytes"] % 8 == 0
+    assert L["count_offset"] == L["record_bytes"] - sharding.RECORD_TRAILER and L["count_offset"] % 8 == 0
+    assert L["send_bytes"] == frames * L["record_bytes"] and L["gathered_bytes"] == n * L["send_bytes"]
+    assert L["frame_record_bytes"] == ((w * h * 3 + 7) & ~7) + 8 and L["frame_count_offset"] == L["frame_record_bytes"] - 8
+    assert L["host_bytes"] == frames * L["frame_record_bytes"] and L["counts_pitch"] == L["send_bytes"]
+    # a synthetic gathered buffer laid out by these numbers reassembles through the mirror: every tile in its place, counts summed
+    rng = np.random.default_rng(n * 1000 + w)
+    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for _ in range(frames)]
+    gathered = np.zeros(L["gathered_bytes"], np.uint8)
+    for d in range(n):
+        for f in range(frames):
+            rec = sharding.make_record(sharding.pack_block(imgs[f], d, n, tw, th), 1000 * f + d)
+            assert rec.size == L["record_bytes"]
+            at = (d * frames + f) * L["record_bytes"]
+            gathered[at:at + rec.size] = rec
+    # the strided column of counts of frame 0, as hipMemcpy2D reads it (pitch = counts_pitch, 8 bytes wide, n rows)
+    col = np.stack([gathered[d * L["counts_pitch"] + L["count_offset"]:d * L["counts_pitch"] + L["count_offset"] + 8] for d in range(n)])
+    assert [int(x) for x in np.ascontiguousarray(col).view(np.uint64).reshape(-1)] == list(range(n))
+    for f, (img, rays) in enumerate(sharding.assemble_records_batch(gathered, frames, w, h, n, tw, th)):
+        assert img.tobytes() == imgs[f].tobytes() and rays == sum(1000 * f + d for d in range(n))
