@@ -608,22 +608,29 @@ def run_ranks(args):
     # without a stalled submission: the HIP runtime creates its hardware queues lazily, ~7 ms each, somewhere in the first
     # dozens of submissions on 16-20 streams (tools/submit_times.py: five such stalls in the first pass over 20 slots,
     # three in the second, none afterwards; a 20-step run that meets two of them is 16 ms late on a 17 ms job).
-    setup_passes = 0
-    for _ in range(8):
-        worst = 0.0
-        for _ in range(B * len(slots)):
-            t_ = time.perf_counter()
-            step()
-            worst = max(worst, time.perf_counter() - t_)
-        fence()
-        setup_passes += 1
-        if n > 1:
-            # every rank must run the SAME number of passes (each pass issues collectives): the verdict is the slowest rank's
-            t = torch.tensor([worst], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            worst = float(t.item())
-        if setup_passes >= 2 and worst < 2e-3:
-            break
+    def settle(at_least=2):
+        """Passes over every slot until one goes through without a stalled submission; returns the number of passes.  Also run in front of
+        every secondary measurement that uses other operations than the main one (a resolve launch and copies on streams that have only
+        carried single-launch frames so far: their first uses stall as well — the exhaustive sweep once read 8.4 instead of 17.9 Grays/s)."""
+        passes = 0
+        for _ in range(8):
+            worst = 0.0
+            for _ in range(B * len(slots)):
+                t_ = time.perf_counter()
+                step()
+                worst = max(worst, time.perf_counter() - t_)
+            fence()
+            passes += 1
+            if n > 1:
+                # every rank must run the SAME number of passes (each pass issues collectives): the verdict is the slowest rank's
+                t = torch.tensor([worst], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                worst = float(t.item())
+            if passes >= at_least and worst < 2e-3:
+                break
+        return passes
+
+    setup_passes = settle()
     for _ in range(args.warmup):
         step()
     fence()
@@ -682,9 +689,8 @@ def run_ranks(args):
     if n == 1 and args.variant == 0 and info["kernel"] == 4 and not sharded and info["spheres_active"] <= 1023 and not args.no_extras:
         p_main = p
         p = r1.make_params(w, h, spp, args.seed, shard=0, num_shards=1, variant=binding.VARIANT_PREFILTER)
-        sweep_steps = max(B * len(slots), args.steps // 2)
-        for _ in range(B * len(slots)):
-            step()
+        sweep_steps = max(B * len(slots), args.steps // 2, 100)  # (its own, longer region: a 20-step burst of this kernel reads 7 % lower, and `steps` says so)
+        settle()
         sweep_elapsed, _, _ = timed(sweep_steps)
         sweep_rate = rays_per_step * sweep_steps / sweep_elapsed
         sweep_line = {"value": sweep_rate / 1e6, "unit": "mrays/s", "steps": sweep_steps,

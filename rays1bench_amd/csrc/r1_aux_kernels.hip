@@ -317,7 +317,7 @@ extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int 
     if (variant == 3 && big)
         variant = 2; // (no diagnostic build of the LDS-tiled sweep)
     // the throughput builds of the product kernels sum their tiles themselves (R1_LAND): a launch through them says on how many XCDs
-    const bool land_kernel = (variant == 2 || variant == 4) && R1_LAND_MODE(mode);
+    const bool land_kernel = variant == 4 && R1_LAND_MODE(mode);
     if (land_kernel != (args->land_res > 0u))
         return hipErrorInvalidValue;
     if (tree)

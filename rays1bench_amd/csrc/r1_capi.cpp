@@ -150,7 +150,7 @@ struct r1_context
     int occupancy[48] = {0}; // [variant + 8 * big + 16 * mode]
     bool pixel_mode = false; // r1_set_pixel_mode
     DevBuf gstack; // blocks per CU of the trace kernel, by variant
-    DevBuf land_spill; // R1_LAND: [waves of the largest grid][136] tiles a wave owes beyond its LDS notes
+    DevBuf land_spill; // R1_LAND: [waves of the grid][tiles of the launch] every wave's list of the tiles it took chunks from
 
     r1_launch_info info;
 };
@@ -777,7 +777,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
         r1_set_error("frame batches run through the throughput kernels only (no PIXEL mode, no diagnostic / reference-form / wavefront variant)");
         return R1_EINVAL;
     }
-    if (batch && !(R1_LAND && (variant == 2 || variant == 4)))
+    if (batch && !(R1_LAND && variant == 4))
     {
         // partial ray counts of the resolve launch: one uint64 per (tile of the batch, workgroup column)
         const size_t cols = ((size_t)p->tile_w * p->tile_h + 255) / 256;
@@ -786,7 +786,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     }
     // tiles resolved inside the trace kernel: the product kernels' launches; the diagnostic builds, the reference-form
     // sweep, the wavefront variant and PIXEL mode keep the round-3 form (records + r1_resolve_kernel, or no records at all)
-    const bool land = (variant == 2 || variant == 4) && R1_LAND_MODE(mode) && c->total_samples > 0;
+    const bool land = variant == 4 && R1_LAND_MODE(mode) && c->total_samples > 0;
     if (!pixel_mode)
     {
         const size_t want = (size_t)(c->total_samples ? c->total_samples : 1) * 16;
@@ -1012,10 +1012,21 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
         a.land.inv_spp = (float)(1.0f / p->spp); // rayweek1.cpp:765
         a.land.error = c->host_word_dev ? (uint32_t *)(c->host_word_dev + 1) : nullptr;
         {
-            const size_t max_blocks = std::max((size_t)blocks, (size_t)c->cus * (size_t)per_cu);
-            if ((rc = ensure(c->land_spill, max_blocks * (R1_BLOCK / 64) * 136 * 4)))
+            // every wave's list of tiles: a row as long as the launch has tiles (the cursors only move forward: a wave meets a tile at
+            // most once; with uneven residency — twenty frames in flight, a frame's first workgroups do most of its work — a
+            // shorter list overflowed at 250 spp)
+            const size_t tiles_all = (size_t)c->n_local_tiles * n_frames;
+            const size_t bytes = (size_t)blocks * (R1_BLOCK / 64) * tiles_all * 4;
+            if (bytes > ((size_t)2 << 30))
+            {
+                r1_set_error("frames in flight: %zu tiles x %lld waves need %zu MB of tile lists; render this frame synchronously or in shards", tiles_all,
+                             (long long)blocks * (R1_BLOCK / 64), bytes >> 20);
+                return R1_ELIMIT;
+            }
+            if ((rc = ensure(c->land_spill, bytes)))
                 return rc;
             a.land.owed_spill = (uint32_t *)c->land_spill.p;
+            a.land.spill_stride = (uint32_t)tiles_all;
         }
         a.num_rays = nullptr;
     }

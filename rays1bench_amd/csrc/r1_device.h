@@ -116,7 +116,8 @@ struct R1LandArgs
     uint32_t n_frames;              // frames of the launch (1: a single frame)
     uint32_t rays_in_out, block_layout;
     float inv_spp;                  // (float)(1.0f / spp), rayweek1.cpp:765
-    uint32_t *owed_spill;           // [waves of the grid][136]: tiles a wave owes beyond the 24 it notes in LDS
+    uint32_t *owed_spill;           // [waves of the grid][spill_stride]: a wave's list of the tiles it took chunks from, beyond the 24 entries it keeps in LDS
+    uint32_t spill_stride;          // = tiles of the launch (a wave meets a tile at most once)
     uint32_t *error;                // page-locked host word (or null): set if a wave gave up on a tile (R1_LAND_MAX_WAIT) — never in a correct run
 };
 

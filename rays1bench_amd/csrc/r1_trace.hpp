@@ -1286,7 +1286,7 @@ __device__ __forceinline__ bool shade_level(const R1TraceArgs &A, Path &p, const
 //     swapped for a mark, and the wave that wins the swap sums the tile — its records sit in this XCD's L2 or in memory, nowhere else —
 //     adds the tile's rays to the frame's count and re-arms the countdown for the next launch.  Of the waves that worked on a tile the
 //     last to get there finds it complete, so every tile is summed.  The wave that takes the frame's last tile off publishes the ray
-//     count.  (A wave whose list is full takes no more samples: it ends early.)
+//     count.  (The list: 24 entries in LDS, the rest in a row of global memory long enough for every tile of the launch.)
 //   * every record carries the launch's tag in its ray-count word: a countdown is not ordered after the stores it counts, so a wave
 //     that finds a record of an earlier launch in a tile it owes simply reads the tile again (past the vector L1: sc0 loads).
 // Per launch, behind the queue pointer (one of two sets, zeroed by the launch after): line x = XCD x's cursor (uint64); line 16 = the
@@ -1294,8 +1294,7 @@ __device__ __forceinline__ bool shade_level(const R1TraceArgs &A, Path &p, const
 #ifndef R1_LAND_EXP
 #define R1_LAND_EXP 0 // measurements only (make tuning EXTRA=-DR1_LAND_EXP=n; frames are NOT valid): 1 no tile is resolved, 2 and no countdown atomics
 #endif
-#define R1_LAND_OWED 24u        // tiles a wave can owe: words of LDS per wave ...
-#define R1_LAND_OWED_SPILL 136u // ... and of its row in the spill area behind them
+#define R1_LAND_OWED 24u        // tiles of a wave's list kept in LDS (the rest: its row of the spill area in global memory)
 #define R1_LAND_LOADS 8      // records of one pixel a lane keeps in flight while it sums a tile (4 registers each; 10 spill in the 72-register builds)
 #define R1_LAND_MAX_XCD 8u
 
@@ -1315,19 +1314,18 @@ __device__ __forceinline__ void land_note(const R1TraceArgs &A, uint32_t *row, c
 {
     const uint32_t at = row[4];
     row[4] = at + 1u;
-    // (past R1_LAND_OWED the wave's row of the spill area; a wave whose list is nearly full takes no more chunks, see the fetch)
+    // (past R1_LAND_OWED the wave's row of the spill area, which has room for every tile of the launch: the XCD's cursor only moves
+    //  forward, so a wave meets a tile at most once — however unevenly the launch's workgroups get their slots, the list cannot overflow)
     if (at < R1_LAND_OWED)
         row[8u + at] = t;
-    else if (at < R1_LAND_OWED + R1_LAND_OWED_SPILL)
+    else
     {
         // (32-bit index on a scalar base: as a 64-bit per-lane address the row's part of it is hoisted out of the tracing loop and spilled to scratch)
         uint32_t tx = threadIdx.x;
         asm volatile("" : "+v"(tx)); // (formed here, not hoisted)
         const uint32_t wave = blockIdx.x * (R1_BLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(tx >> 6));
-        ((r1_gu32 *)A.land.owed_spill)[wave * R1_LAND_OWED_SPILL + (at - R1_LAND_OWED)] = t;
+        ((r1_gu32 *)A.land.owed_spill)[(size_t)wave * A.land.spill_stride + at] = t;
     }
-    else if (A.land.error)
-        *A.land.error = 1u;
 }
 
 // subtract n finished samples from tile t's countdown: fire and forget (a RETURNING atomic here — "who reaches zero owes the tile" —
@@ -1456,7 +1454,7 @@ __device__ __forceinline__ void land_exit(const R1TraceArgs &A, uint32_t *row, c
     }
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): this wave's record stores, subtractions and spilled list entries have been performed
     __builtin_amdgcn_wave_barrier();
-    const uint32_t touched = min((uint32_t)__builtin_amdgcn_readfirstlane((int)row[4]), R1_LAND_OWED + R1_LAND_OWED_SPILL);
+    const uint32_t touched = (uint32_t)__builtin_amdgcn_readfirstlane((int)row[4]);
     for (uint32_t base = 0; base < touched; base += 64u) // (wave-uniform; one trip unless the list spilled)
     {
         const uint32_t i = base + (uint32_t)lane;
@@ -1471,7 +1469,7 @@ __device__ __forceinline__ void land_exit(const R1TraceArgs &A, uint32_t *row, c
             else
             {
                 const uint32_t wave = blockIdx.x * (R1_BLOCK / 64) + (threadIdx.x >> 6);
-                t = ((const r1_gu32 *)A.land.owed_spill)[wave * R1_LAND_OWED_SPILL + (i - R1_LAND_OWED)];
+                t = ((const r1_gu32 *)A.land.owed_spill)[(size_t)wave * A.land.spill_stride + i];
             }
             // (device scope: the countdowns are only ever touched by atomics, which are performed behind the L2s)
             c = __hip_atomic_load(A.land_cnt + t * R1_LAND_CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1536,10 +1534,10 @@ template <int VARIANT, bool STATS, bool BIG, int MODE>
 __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MODE>::value)) r1_trace_kernel(const R1TraceArgs A)
 {
     constexpr bool LAT = MODE == 1, PIX = MODE == 2, BATCH = MODE == 3; // MODE 3 = MODE 0 whose queue spans the frames of a batch
-    // tiles resolved inside the kernel: the throughput builds of the product kernels (frames in flight, MODE 0 / 3); a
-    // launch through them is a landing launch (r1_launch_trace checks).  The synchronous frame keeps the resolve launch: its tiles would
-    // have to be dealt to the XCDs dynamically (the XCDs of one chip run this kernel up to 20 % apart), see DESIGN.md §4.10.
-    constexpr bool LAND = R1_LAND_MODE(MODE) && !STATS && VARIANT != 1;
+    // tiles resolved inside the kernel: the throughput builds of the tree kernels (frames in flight, MODE 0 / 3); a
+    // launch through them is a landing launch (r1_launch_trace checks).  The synchronous frame keeps the resolve launch (measured
+    // slower with its tiles summed at wave exit, R1_LAND_SYNC), and so do the exhaustive sweep's kernels.
+    constexpr bool LAND = R1_LAND_MODE(MODE) && !STATS && VARIANT == 4; // (the exhaustive sweep keeps the resolve launch: its loop pays 14 % for the bookkeeping, 16.6 against 19.2 Grays/s)
     const uint32_t tb = blockIdx.x, n_tb = gridDim.x;
     // LAND: this workgroup's XCD (HW_REG_XCC_ID), the tiles of the launch
     const uint32_t xcd = LAND ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(xcc_id() & 7u)) : 0u;
@@ -1701,8 +1699,6 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
                         base = atomicAdd(A.queue + 32u * home, 1u);
                     base = (__builtin_amdgcn_readfirstlane(base) * A.nq + home) * want;
                 }
-                else if (LAND && (uint32_t)__builtin_amdgcn_readfirstlane((int)row[4]) + 3u >= R1_LAND_OWED)
-                    base = q_total; // this wave's notes of owed tiles are (nearly) full: it takes no more samples, ends early and sums them
                 else if (LAND)
                 {
                     // guided as the single queue is: ~ what is left of the launch / (2 waves) — here: the tiles nobody has claimed yet

@@ -122,6 +122,15 @@ def test_config4_full_size_1200x800x250_properties_and_oracle_spots(renderer):
     # and the exhaustive sweep gives the same frame
     img3, rays3, _ = renderer.render(r1.make_params(w, h, spp, seed, variant=binding.VARIANT_PREFILTER))
     assert rays3 == rays and img3.tobytes() == img.tobytes()
+    # the same frame through the throughput entry point (ONE launch: the trace kernel sums its own tiles, DESIGN.md §4.10 — at 250 spp
+    # a wave takes ~50 chunks of ~3 000 samples: the chunk size follows the length of the wave's list of tiles), twice in a row
+    hf = binding.HostFrames(w, h, 1)
+    for _ in range(2):
+        hf._all[:] = 0x5A
+        renderer.render_async(p, hf)
+        renderer.sync()
+        assert hf.rays(0) == rays and hf.image(0).tobytes() == img.tobytes()
+    hf.close()
 
 
 # ---- configs 2/3 at full size through 8 shards --------------------------------------------------
@@ -188,6 +197,12 @@ def test_config5_full_size_through_the_tree_properties_and_oracle_spots(renderer
     assert rays2 == rays and img2.tobytes() == img.tobytes()
     acc, total = union_of_shards(renderer, w, h, spp, seed, 8, binding.VARIANT_DEFAULT)
     assert total == rays and acc.tobytes() == img.tobytes()
+    # the throughput entry point (big-scene kernels, tiles summed inside the launch: 2 040 tiles claimed by the XCDs' cursors)
+    hf = binding.HostFrames(w, h, 1)
+    renderer.render_async(p, hf)
+    renderer.sync()
+    assert hf.rays(0) == rays and hf.image(0).tobytes() == img.tobytes()
+    hf.close()
 
 
 # ---- adversarial families (VERDICT r01 / ADVICE r01) --------------------------------------------------

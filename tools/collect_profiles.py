@@ -8,7 +8,7 @@ import json
 import os
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles", tag)
@@ -27,7 +27,7 @@ tp, lat, pix, sw = ("r1_trace_kernel<4, false, false, 0>", "r1_trace_kernel<4, f
                     "r1_trace_kernel<2, false, false, 0>")
 cmd = "rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 --inflight 1 (tools/profile_round.sh); mean per dispatch"
 counters = {"command": cmd, "workload": "large 1200x800x10",
-            "tree kernel, frames in flight (MODE 0, 254 workgroups)": {k: v[0] for k, v in {**means("pmc_sq1", tp), **means("pmc_sq2", tp)}.items()},
+            "tree kernel, frames in flight (MODE 0)": {k: v[0] for k, v in {**means("pmc_sq1", tp), **means("pmc_sq2", tp)}.items()},
             "tree kernel, synchronous frame (MODE 1, 1536 workgroups)": {k: v[0] for k, v in {**means("pmc_sq1", lat), **means("pmc_sq2", lat)}.items()},
             "exhaustive sweep, frames in flight (MODE 0)": {k: v[0] for k, v in {**means("pmc_sq1", sw), **means("pmc_sq2", sw)}.items()},
             "note": "SQ_INSTS_VALU = VALU wave-instructions per launch (one frame); round 1's tree kernel: 888 M."}
@@ -87,10 +87,10 @@ traffic = {"workload": "large 1200x800x10", "kernel": "r1_trace_kernel<4,false,f
            "correction": "MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide coalesced read -> x2; WRITE_SIZE taken as is",
            "hbm_bytes_per_launch": hb(f, w),
            "other_kernels": {"synchronous frame (MODE 1)": hb(fl, wl), "exhaustive sweep (MODE 0)": hb(fs, ws), "PIXEL mode (MODE 2, r1_set_pixel_mode)": hb(fp, wp)},
-           "valu_wave_instructions_per_launch": counters["tree kernel, frames in flight (MODE 0, 254 workgroups)"]["SQ_INSTS_VALU"],
+           "valu_wave_instructions_per_launch": counters["tree kernel, frames in flight (MODE 0)"]["SQ_INSTS_VALU"],
            "valu_source": f"profiles/{tag}/pmc_counters_tree_kernel.json (rocprofv3 --pmc SQ_INSTS_VALU ..., same command)",
-           "valu_active_lane_fraction": counters["tree kernel, frames in flight (MODE 0, 254 workgroups)"]["SQ_THREAD_CYCLES_VALU"]
-           / (counters["tree kernel, frames in flight (MODE 0, 254 workgroups)"]["SQ_ACTIVE_INST_VALU"] * 64),
+           "valu_active_lane_fraction": counters["tree kernel, frames in flight (MODE 0)"]["SQ_THREAD_CYCLES_VALU"]
+           / (counters["tree kernel, frames in flight (MODE 0)"]["SQ_ACTIVE_INST_VALU"] * 64),
            "note": "the trace kernel writes one 16-byte record per pixel-sample (9.6 M x 16 B = 153.6 MB) and reads the node table + sphere pairs through L1/L2: "
                    "HBM reads are noise.  The synchronous-frame kernel writes more (64-sample chunks per wave: more partial lines).  PIXEL mode writes the resolved pixels only."}
 json.dump(traffic, open(f"{root}/profiles/pmc_traffic.json", "w"), indent=1)

@@ -6,7 +6,7 @@
 #   3. SQ counters of the throughput-mode trace kernel (instruction counts, busy / wait cycles)
 #   4. the bench line itself (with cpu_baseline), the other BASELINE configs on one GPU, emulated per-rank loads
 #   5. diagnostics: traversal counters, per-wave timeline of a synchronous frame, tree against sweep by sphere count, issue-cost and atomic micro-benchmarks
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT && mkdir -p $OUT
