@@ -102,7 +102,7 @@ def set_lib_path(path):
 
 def build(verbose=False):
     """Compiles librays1.so and rayweek1_hip in-tree with hipcc --offload-arch=gfx950."""
-    subprocess.check_call(["make", "-C", CSRC] + ([] if verbose else ["-s"]))
+    subprocess.check_call(["make", "-j4", "-C", CSRC] + ([] if verbose else ["-s"]))
 
 
 # every symbol include/rays1.h declares: (name, restype, argtypes)
