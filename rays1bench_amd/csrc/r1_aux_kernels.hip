@@ -308,7 +308,7 @@ extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int 
     // dynamic LDS of the tree kernels: the traversal stack, one entry per inner node on a path, and (small scenes) the node table
     const bool big = big_in != 0; // 32-bit hit indices, attenuation stack in the global workspace
     const bool tree = variant == 4 || variant == 5;
-    const size_t trav = tree ? (size_t)args->bvh_depth * R1_BLOCK * (big ? sizeof(uint32_t) : sizeof(uint16_t)) + (size_t)args->bvh_lds_f4 * 16 : 0;
+    const size_t trav = tree ? (size_t)args->bvh_depth * R1_BLOCK * (big ? sizeof(uint32_t) : sizeof(uint16_t)) + (size_t)args->bvh_lds_f4 * 16 + R1_ENTRY_LDS_BYTES(args->entry_lds) : 0;
     if (mode != r1_trace_mode(variant, big_in, mode))
         return hipErrorInvalidValue; // the caller sizes its arguments by the mode: it must be the one that is built
     const int batch = args->batch != nullptr; // frame batches: the MODE 3 build of the throughput kernels (variants 2 and 4 only)
@@ -319,6 +319,9 @@ extern "C" hipError_t r1_launch_trace(const R1TraceArgs *args, int variant, int 
     // the throughput builds of the product kernels sum their tiles themselves (R1_LAND): a launch through them says on how many XCDs
     const bool land_kernel = variant == 4 && R1_LAND_MODE(mode);
     if (land_kernel != (args->land_res > 0u))
+        return hipErrorInvalidValue;
+    // (the tree kernels look a primary ray's entry node up in args->bvh_entry whenever the tree has a root step: never launch them without)
+    if (tree && R1_ENTRY_MODE(mode) && args->scene.bvh_root_leaf != 0u && args->bvh_entry == nullptr)
         return hipErrorInvalidValue;
     if (tree)
         return big ? r1_tu_tree_big_launch(args, variant, mode, batch, blocks, trav, stream) : r1_tu_tree_small_launch(args, variant, mode, batch, blocks, trav, stream);

@@ -150,6 +150,12 @@ struct r1_context
     int occupancy[48] = {0}; // [variant + 8 * big + 16 * mode]
     bool pixel_mode = false; // r1_set_pixel_mode
     DevBuf gstack; // blocks per CU of the trace kernel, by variant
+    // per-tile entry nodes for primary rays (R1_ENTRY): the tree's nodes on the host, the device table, what it was computed for
+    std::vector<float> bvh_nodes_host;
+    DevBuf bvh_entry;
+    r1_params entry_key;
+    int entry_frames = 0;
+    bool entry_valid = false;
     DevBuf land_spill; // R1_LAND: [waves of the grid][tiles of the launch] every wave's list of the tiles it took chunks from
 
     r1_launch_info info;
@@ -262,7 +268,7 @@ extern "C" void r1_destroy(r1_context *c)
     release(c->sweep), release(c->exact), release(c->shade), release(c->mat), release(c->members);
     release(c->bvh_nodes), release(c->bvh_prims), release(c->bvh_ids);
     release(c->wf_paths), release(c->wf_hits), release(c->wf_queue), release(c->wf_counts);
-    release(c->land_spill), release(c->gstack), release(c->counters), release(c->samples), release(c->image), release(c->batch_rays);
+    release(c->bvh_entry), release(c->land_spill), release(c->gstack), release(c->counters), release(c->samples), release(c->image), release(c->batch_rays);
     release(c->wave_log);
     if (c->host_word)
         (void)hipHostFree(c->host_word);
@@ -590,6 +596,8 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
     R1_HIP(hipMemcpyAsync(c->bvh_prims.p, bvh.prims.data(), bvh.prims.size() * 4, hipMemcpyHostToDevice, c->stream));
     R1_HIP(hipMemcpyAsync(c->bvh_ids.p, bvh.ids.data(), bvh.ids.size() * 4, hipMemcpyHostToDevice, c->stream));
     R1_HIP(hipStreamSynchronize(c->stream)); // the host vectors go out of scope
+    c->bvh_nodes_host = bvh.nodes;
+    c->entry_valid = false;
     c->n_bvh_nodes = (uint32_t)(bvh.nodes.size() / 16);
     c->n_bvh_leaves = bvh.n_leaves;
     c->bvh_depth = bvh.max_depth;
@@ -705,6 +713,150 @@ struct Batch
     uint32_t seed_stride = 0;
     size_t out_stride = 0, rays_offset = 0;
 };
+
+// ---- per-tile entry nodes for primary rays (R1_ENTRY) ---------------------------------------------------------
+// All primary rays of a 32 x 32 tile leave a small lens disk through a small rectangle of the focal plane: a narrow beam.  For every
+// tile of the launch the deepest node is found below which ALL of them stay, and a primary ray starts its walk there instead of at the
+// root's inner child (bvh_advance's root step still tests the root's leaf — the ground and the big balls — and the inner child's box).
+// Exactness: a subtree is left out only if no ray of the beam can pass the kernel's box test of its root, judged CONSERVATIVELY — the
+// box inflated by the largest pad any of these rays gets (the pad makes the boxes conservative with respect to the reference's fp32
+// sphere test, r1_bvh.cpp) plus a margin for the test's own rounding, against the four side planes of the beam pushed outwards by the
+// lens radius — so the walk from the root would not have entered it either: same offers, same minimum, same pixels.
+static void beam_planes(const R1DeviceCamera &cam, double s0, double s1, double t0, double t1, double n[4][3], double &d_plane)
+{
+    double q[4][3];
+    const double ss[4] = {s0, s1, s1, s0}, tt[4] = {t0, t0, t1, t1};
+    for (int k = 0; k < 4; ++k)
+        for (int a = 0; a < 3; ++a)
+            q[k][a] = (double)cam.lower_left[a] + ss[k] * cam.horizontal[a] + tt[k] * cam.vertical[a] - cam.origin[a]; // corner directions from the lens centre
+    // side plane k contains the lens centre and corners k, k + 1; its normal points away from the opposite corner
+    for (int k = 0; k < 4; ++k)
+    {
+        const double *a = q[k], *b = q[(k + 1) & 3], *c = q[(k + 2) & 3];
+        double m[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+        const double len = sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+        double sgn = (m[0] * c[0] + m[1] * c[1] + m[2] * c[2]) > 0 ? -1.0 : 1.0;
+        for (int i = 0; i < 3; ++i)
+            n[k][i] = len > 0 ? sgn * m[i] / len : 0.0;
+    }
+    // distance of the focal plane from the lens centre (along its normal): every target point is at least that far away
+    double w[3] = {cam.horizontal[1] * (double)cam.vertical[2] - cam.horizontal[2] * (double)cam.vertical[1],
+                   cam.horizontal[2] * (double)cam.vertical[0] - cam.horizontal[0] * (double)cam.vertical[2],
+                   cam.horizontal[0] * (double)cam.vertical[1] - cam.horizontal[1] * (double)cam.vertical[0]};
+    const double wl = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    d_plane = wl > 0 ? fabs((w[0] * q[0][0] + w[1] * q[0][1] + w[2] * q[0][2]) / wl) : 0.0;
+}
+
+// may any ray of the beam pass the (inflated) box {m, e}?  false only when one side plane has the whole box outside
+static bool beam_may_hit(const R1DeviceCamera &cam, const double n[4][3], double d_plane, const double m[3], const double e[3])
+{
+    const double r = fabs((double)cam.lens_radius);
+    double rel[3], far2 = 0;
+    for (int a = 0; a < 3; ++a)
+    {
+        rel[a] = m[a] - cam.origin[a];
+        const double f = fabs(rel[a]) + e[a];
+        far2 += f * f;
+    }
+    // a point of a beam ray at parameter L (1 = the focal plane) lies within |1 - L| r of the cone from the lens CENTRE; inside the box
+    // L <= (farthest corner + r) / (focal distance - r)
+    const double lmax = d_plane > 2 * r ? (sqrt(far2) + r) / (d_plane - r) : 1e30;
+    const double rho = r * std::max(1.0, lmax - 1.0);
+    if (!(rho < 1e20))
+        return true;
+    for (int k = 0; k < 4; ++k)
+    {
+        double lo = 0;
+        for (int a = 0; a < 3; ++a)
+            lo += n[k][a] * rel[a] - fabs(n[k][a]) * e[a];
+        if (lo > rho)
+            return false;
+    }
+    return true;
+}
+
+// entry[j] for every tile j of the launch (frame-major as the queue; the frames of a batch share the camera): a child reference in the
+// kernel's form (16-bit for the small-scene kernels); R1_BVH_DONE (all ones) where the beam misses the inner child altogether
+static void compute_entries(const r1_context *c, const r1_params *p, int n_frames, bool ref16, std::vector<uint32_t> &out)
+{
+    const uint32_t nlt = c->n_local_tiles;
+    out.assign((size_t)nlt * n_frames, 0xFFFFFFFFu);
+    const size_t n_nodes = c->bvh_nodes_host.size() / 16;
+    if (!c->bvh_root_leaf || n_nodes < 1 || nlt == 0)
+        return;
+    const float *N = c->bvh_nodes_host.data();
+    auto child = [&](uint32_t node, int k) { uint32_t v; memcpy(&v, N + 16 * (size_t)node + 14 + k, 4); return v; };
+    auto form = [&](uint32_t ref) { return ref16 && ref != 0xFFFFFFFFu ? (((ref >> 16) & 0xF000u) | (ref & 0x0FFFu)) : ref; }; // r1_ref16 (r1_trace.hpp)
+    const uint32_t other = child(0, c->bvh_root_leaf == 1 ? 1 : 0);
+    static const int entry_off = (int)r1_knob("R1_ENTRY_OFF", 0); // tuning: every tile starts at the root's inner child
+    if ((other & 0x80000000u) || entry_off)
+    {
+        out.assign((size_t)nlt * n_frames, form(other));
+        return;
+    }
+    const int tiles_x = (p->width + p->tile_w - 1) / p->tile_w;
+    const double r = fabs((double)c->cam.lens_radius);
+    double oc2 = 0, o1 = 0;
+    for (int a = 0; a < 3; ++a)
+        oc2 += ((double)c->cam.origin[a] - c->bvh_centre[a]) * ((double)c->cam.origin[a] - c->bvh_centre[a]), o1 += fabs((double)c->cam.origin[a]);
+    const double r2max = (sqrt(oc2) + r) * (sqrt(oc2) + r); // largest |o - C|^2 of a primary ray's origin
+    long depth_sum = 0, missed = 0;
+    for (uint32_t lt = 0; lt < nlt; ++lt)
+    {
+        const int tile = p->shard + (int)lt * p->num_shards;
+        const int x0 = (tile % tiles_x) * p->tile_w, y0 = (tile / tiles_x) * p->tile_h;
+        const int tw = std::min(p->tile_w, p->width - x0), th = std::min(p->tile_h, p->height - y0);
+        double n[4][3], d_plane;
+        // (x + jitter) / W with jitter in [0, 1); a hair of slack for the fp32 products of Camera::getRay
+        beam_planes(c->cam, (x0 - 1e-3) / p->width, (x0 + tw + 1e-3) / p->width, (y0 - 1e-3) / p->height, (y0 + th + 1e-3) / p->height, n, d_plane);
+        uint32_t x = other; // descend while exactly one child can be met and it is an inner node
+        int levels = 0;
+        for (;; ++levels)
+        {
+            const float *q = N + 16 * (size_t)x;
+            const double A = q[12], K = q[13];
+            int hits = 0, which = -1;
+            for (int k = 0; k < 2; ++k)
+            {
+                const double m[3] = {q[0 + k], q[2 + k], q[4 + k]};
+                double pad;
+                if (c->bvh_pad_local)
+                {
+                    double s2 = 0; // |m0 + m1 - 2 o|^2 at its largest over the lens disk
+                    const double sv[3] = {(double)q[0] + q[1] - 2.0 * c->cam.origin[0], (double)q[2] + q[3] - 2.0 * c->cam.origin[1], (double)q[4] + q[5] - 2.0 * c->cam.origin[2]};
+                    for (int a = 0; a < 3; ++a)
+                        s2 += sv[a] * sv[a];
+                    pad = A * (sqrt(s2) + 2 * r) * (sqrt(s2) + 2 * r) + K;
+                }
+                else
+                    pad = A * r2max + K;
+                // margin: the slab test's rounding (relative 2^-20 of the coordinates involved is generous) and v_rcp_f32's 1 ulp
+                const double margin = 1e-5 * (fabs(m[0]) + fabs(m[1]) + fabs(m[2]) + o1 + 1.0) + 1e-4;
+                const double e[3] = {q[6 + k] * 1.0001 + pad * 1.001 + margin, q[8 + k] * 1.0001 + pad * 1.001 + margin, q[10 + k] * 1.0001 + pad * 1.001 + margin};
+                if (beam_may_hit(c->cam, n, d_plane, m, e))
+                    ++hits, which = k;
+            }
+            if (hits == 0)
+            {
+                x = 0xFFFFFFFFu; // nothing of the lattice can be met: the walk is over after the root step
+                break;
+            }
+            if (hits == 2)
+                break;
+            const uint32_t cref = child(x, which);
+            x = cref;
+            if (cref & 0x80000000u)
+                break; // a leaf: tested directly
+        }
+        depth_sum += levels + (x == 0xFFFFFFFFu ? 1 : 0), missed += x == 0xFFFFFFFFu;
+        for (int f = 0; f < n_frames; ++f)
+            out[(size_t)f * nlt + lt] = form(x);
+    }
+    static const int print = (int)r1_knob("R1_ENTRY_PRINT", 0);
+    if (print)
+        fprintf(stderr, "rays1: entry nodes: %u tiles, %.2f levels below the root's inner child on average, %ld tiles whose beam misses it\n", nlt,
+                (double)depth_sum / nlt, missed);
+}
 
 // Where the caller finally wants the frame, if the device can write there (page-locked host memory): launches that resolve their own
 // tiles (R1_LAND) store the pixels and the count there directly and set `used`; the entry point then enqueues no copy.
@@ -853,6 +1005,25 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
         static const int coop_env = (int)r1_knob("R1_COOP_LANES", -1);
         a.coop_lanes = coop_env >= 0 ? (uint32_t)coop_env : R1_COOP_LANES;
     }
+    a.bvh_entry = nullptr, a.entry_lds = 0;
+    if (R1_ENTRY && (variant == 4 || variant == 5) && c->bvh_root_leaf && c->n_local_tiles)
+    {
+        // per-tile entry nodes of the primary rays (compute_entries): once per (scene, camera, tiling, frames of the launch, reference form)
+        const int form = big_scene_ ? 2 : 1;
+        if (!c->entry_valid || c->entry_frames != n_frames * 4 + form || !same_tiling(c->entry_key, *p))
+        {
+            std::vector<uint32_t> tab;
+            compute_entries(c, p, n_frames, !big_scene_, tab);
+            R1_HIP(hipDeviceSynchronize()); // (launches still reading the previous table: a change of tiling is rare)
+            if ((rc = ensure(c->bvh_entry, tab.size() * 4)))
+                return rc;
+            R1_HIP(hipMemcpy(c->bvh_entry.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+            c->entry_valid = true, c->entry_frames = n_frames * 4 + form, c->entry_key = *p;
+        }
+        a.bvh_entry = (const uint32_t *)c->bvh_entry.p;
+        static const int entry_lds_env = (int)r1_knob("R1_ENTRY_LDS", 1); // tuning: 0 = the table stays in global memory
+        a.entry_lds = (!big_scene_ && !batch && entry_lds_env && c->n_local_tiles <= R1_ENTRY_LDS_MAX) ? c->n_local_tiles : 0u;
+    }
     a.samples = (float4 *)c->samples.p;
     // The frame's last launch (resolve) publishes the ray count and zeroes the counter block for the next frame, which
     // saves the two memset launches in front of every frame (they cost nothing to execute and ~10 us each to dispatch:
@@ -875,7 +1046,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     const int occ_slot = variant + 8 * big + 16 * mode;
     if (c->occupancy[occ_slot] == 0)
         R1_HIP(r1_trace_occupancy(variant, big, mode,
-                                  (variant == 4 || variant == 5) ? (size_t)a.bvh_depth * R1_BLOCK * (big ? 4 : 2) + (size_t)a.bvh_lds_f4 * 16 : 0,
+                                  (variant == 4 || variant == 5) ? (size_t)a.bvh_depth * R1_BLOCK * (big ? 4 : 2) + (size_t)a.bvh_lds_f4 * 16 + (big ? 0 : R1_ENTRY_LDS_BYTES(R1_ENTRY_LDS_MAX)) : 0,
                                   &c->occupancy[occ_slot]));
     int per_cu = c->occupancy[occ_slot];
     if (per_cu < 1)

@@ -53,6 +53,18 @@
 #ifndef R1_LAND
 #define R1_LAND 1
 #endif
+// per-tile entry nodes: a PRIMARY ray starts its walk below the root's inner child at the deepest node all primary rays of
+// its 32 x 32 tile stay under (computed on the host per camera and tiling, r1_capi.cpp compute_entries); 0: every walk starts at that child.
+// Built, bit-identical, measured and NOT adopted (round 4): 9 % fewer node visits per ray (5.41 -> 4.91 on large 1200x800x10; 42 % of the
+// tiles' primary rays are done after the root step) but 5 % more wave iterations — the primary rays' shorter walks do not shorten the LONGEST
+// walk of a wave, which sets the trips of the divergent loops — and the same Grays/s on every BASELINE configuration within the run-to-run
+// noise (profiles/r04/entry_nodes_ab.txt).  `make tuning EXTRA=-DR1_ENTRY=1` builds it; tools/entry_ab.sh runs the parity tests and the A/B.
+#ifndef R1_ENTRY
+#define R1_ENTRY 0
+#endif
+#define R1_ENTRY_LDS_MAX 2048u // tiles per launch up to which the small-scene kernels keep the entry table in LDS (4 KB)
+#define R1_ENTRY_LDS_BYTES(n) ((((size_t)(n) * 2u) + 15u) & ~(size_t)15u)
+#define R1_ENTRY_MODE(mode) (R1_ENTRY && ((mode) == 0 || (mode) == 3 || (mode) == 1))
 #ifndef R1_LAND_SYNC
 #define R1_LAND_SYNC 0 // 1: the synchronous frame's kernels (MODE 1) too — measured and not adopted: 1.276 against 1.077 ms on the device (the tiles a wave owes are summed at ITS exit, i.e. at the end of the frame's critical path; the resolve launch sums all 950 in 26 us with the whole chip), profiles/r04/land_sync_frame.txt
 #endif
@@ -204,6 +216,8 @@ struct R1TraceArgs
     uint32_t *land_cnt;           // [n_frames * n_local_tiles] x R1_LAND_CNT_STRIDE words: samples each tile still lacks; the tracing waves subtract, the wave that
                                   // owes the tile re-arms
     R1LandArgs land;
+    uint32_t entry_lds;           // R1_ENTRY, small-scene kernels, single frames: the workgroups keep the table as 16-bit words in LDS behind their node table (0: read from bvh_entry)
+    const uint32_t *bvh_entry;    // R1_ENTRY: [n_frames * n_local_tiles] child reference (the kernel's form) a primary ray of that tile starts at after the root step
     uint32_t coop_lanes;          // small scenes: once the queue is empty, a wave with <= coop_lanes live paths tests each of them
                                   // against ALL spheres, 64 at a time across the wave (cooperative_sweep), instead of walking the tree
                                   // with 60 lanes masked off: the frame's tail is a few 51-bounce chains, and this shortens a step

@@ -727,9 +727,12 @@ __device__ __forceinline__ void trav_start(Trav &t)
 // utilisation of the node / leaf steps 0.53 / 0.69 -> 0.74 / 0.75, and 5 % SLOWER once the node table sat in LDS, because
 // the vote costs ~20 VALU instructions per trip; removed in round 3)
 // LN: the node table is read from `lnodes`, the workgroup's copy in LDS (the trace kernel on small scenes), instead of S.bvh_nodes.
-template <bool STATS, bool CARRY, bool LN, typename TS>
+// ENTRY: `entry_at` (null for every ray but a primary one) points at the reference the walk goes on at after the root step instead of
+// the root's inner child: the deepest node every primary ray of the tile stays under (r1_capi.cpp compute_entries).
+template <bool STATS, bool CARRY, bool LN, typename TS, bool ENTRY = false>
 __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, const V3 d, Trav &tv, TS *trav, const int tid,
-                                            const uint32_t n_alive, unsigned long long *wstat, const float4 *lnodes /* LDS */, const uint32_t top = 0u /* !LN: nodes [0, top) are in lnodes */)
+                                            const uint32_t n_alive, unsigned long long *wstat, const float4 *lnodes /* LDS */, const uint32_t top = 0u /* !LN: nodes [0, top) are in lnodes */,
+                                            const uint32_t *entry_tab = nullptr, const uint32_t entry_idx = 0xFFFFFFFFu, const uint16_t *entry_lds = nullptr /* LDS; null: entry_tab */)
 {
     const float4 *__restrict__ nodes = S.bvh_nodes;
     const float4 *__restrict__ prims = S.bvh_prims;
@@ -820,7 +823,8 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
     {
         const int k = root_leaf == 1u ? 1 : 0; // column of the OTHER child in the node's rows
         const float *nf = (const float *)lnodes; // node 0: always in the workgroup's LDS copy (big scenes keep the top of the tree there: at least node 0, r1_capi.cpp)
-        const uint32_t leaf = __float_as_uint(nf[14 + (1 - k)]), other = __float_as_uint(nf[14 + k]);
+        const uint32_t leaf = __float_as_uint(nf[14 + (1 - k)]);
+        uint32_t other = __float_as_uint(nf[14 + k]);
         const uint32_t lp = (leaf >> COUNT_SHIFT) & 7u;
         if (STATS)
         {
@@ -844,6 +848,16 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
         }
         float tn;
         const bool h = bvh_box(nf[0 + k], nf[2 + k], nf[4 + k], nf[6 + k], nf[8 + k], nf[10 + k], pa, oi, inv, ainv, best, tn);
+        if (ENTRY && entry_idx != 0xFFFFFFFFu && h)
+        {
+            if (LN && entry_lds != nullptr) // (wave-uniform)
+            {
+                other = entry_lds[entry_idx];
+                other = other == 0xFFFFu ? R1_BVH_DONE : other;
+            }
+            else
+                other = ((const r1_gu32 *)entry_tab)[entry_idx];
+        }
         cur = h ? other : R1_BVH_DONE;
         // (the sibling's own visit taken into this step as well — `if (cur < LEAF_BIT) visit_node();` here — measured 35.5 against 36.2
         //  Grays/s: a generic visit runs at 0.54 lane utilisation inside the loop and at the ~0.34 of the starting lanes out here)
@@ -1604,6 +1618,9 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
         // the thread that copied that row: program order; outside the loop, where the test made the compiler peel and unroll the copy)
         if (LN && tid == 3)
             ((float *)dst)[13] = __uint_as_float(A.scene.bvh_root_leaf);
+        if (LN && !BATCH && R1_ENTRY_MODE(MODE) && A.entry_lds) // the primary rays' entry nodes, 16 bits each (all ones: the walk is over after the root step)
+            for (uint32_t i = (uint32_t)tid; i < A.entry_lds; i += R1_BLOCK)
+                ((uint16_t *)(dst + A.bvh_lds_f4))[i] = (uint16_t)A.bvh_entry[i];
         __syncthreads();
     }
 
@@ -1858,7 +1875,11 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
         else if (VARIANT == 4)
         {
             // while-while with carry-over
-            bvh_advance<STATS, true, LN, TS>(A.scene, p.o, p.d, tv, (TS *)s_trav, tid, (uint32_t)__popcll(live_now), wstat, lnodes, top);
+            constexpr bool ENTRY = R1_ENTRY_MODE(MODE);
+            // (a primary ray that starts its walk: depth 0 and at the root)
+            const uint32_t entry_idx = ENTRY && p.depth == 0 && tv.cur == 0u ? fastdiv(p.k, A.div_full) : 0xFFFFFFFFu;
+            bvh_advance<STATS, true, LN, TS, ENTRY>(A.scene, p.o, p.d, tv, (TS *)s_trav, tid, (uint32_t)__popcll(live_now), wstat, lnodes, top, A.bvh_entry, entry_idx,
+                                                    (LN && !BATCH && A.entry_lds) ? (const uint16_t *)(lnodes + A.bvh_lds_f4) : nullptr);
             ready = alive && tv.cur == R1_BVH_DONE;
             if (tv.best_id != 0xFFFFFFFFu)
                 t_hit = tv.best, hit = (int)tv.best_id;

@@ -18,6 +18,11 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# tools/entry_ab.sh and friends: run the GPU parity tests against another build of the library (an experiment's librays1_tuning.so)
+if os.environ.get("R1_TEST_LIB"):
+    from rays1bench_amd import binding as _binding
+    _binding.set_lib_path(os.environ["R1_TEST_LIB"])
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

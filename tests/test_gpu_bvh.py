@@ -414,3 +414,58 @@ def test_non_finite_spheres_are_never_hit(renderer):
     for v in (BVH, binding.VARIANT_PREFILTER, binding.VARIANT_REFERENCE):
         got = renderer.render_samples(r1.make_params(w, h, spp, 2, variant=v))
         assert got[1] == orays and got[2].tobytes() == osamples.tobytes(), v
+
+
+# ---- per-tile entry nodes --------------------------------------------------------------------------------------
+
+
+def _look(lookfrom, lookat, vfov, aspect, aperture, focus, vup=(0, 1, 0)):
+    """the 22 floats of a camera built as the reference's Camera constructor does (rayweek1.cpp:365-380), in numpy"""
+    f = np.float32
+    lf, la, up = (np.asarray(x, f) for x in (lookfrom, lookat, vup))
+    hh = f(np.tan(np.deg2rad(vfov) / 2))
+    hw = f(aspect) * hh
+    w = lf - la
+    w = w / np.linalg.norm(w)
+    u = np.cross(up, w)
+    u = u / np.linalg.norm(u)
+    v = np.cross(w, u)
+    fo = f(focus)
+    ll = lf - hw * fo * u - hh * fo * v - fo * w
+    return np.concatenate([lf, ll, 2 * hw * fo * u, 2 * hh * fo * v, u, v, w, [f(aperture / 2)]]).astype(f)
+
+
+ENTRY_CAMERAS = {
+    "reference": None,
+    "wide lens": ((13, 2, 3), (0, 0, 0), 20, 0.1 * 40, 10.0),           # aperture 4: beams as wide as the lattice cells
+    "inside the lattice": ((0.3, 0.25, 0.4), (4, 0.2, 1), 70, 0.05, 3.0),  # the origin between the small spheres
+    "looking away": ((13, 2, 3), (26, 4, 6), 30, 0.1, 10.0),            # the lattice behind the camera
+    "from above": ((0.5, 30, 0.5), (0, 0, 0), 40, 0.3, 30.0, (0, 0, -1)),
+    "grazing": ((-14, 0.21, -14), (14, 0.2, 14), 8, 0.0, 5.0),          # pinhole along the ground through the whole lattice
+    "focus behind the origin": ((6, 1, 2), (0, 0.2, 0), 50, 1.5, 0.6),  # focal plane closer than the lens is wide
+}
+
+
+@pytest.mark.parametrize("cam", list(ENTRY_CAMERAS))
+@pytest.mark.parametrize("name,w,h,spp,tile", [("large", 192, 128, 3, 32), ("large", 100, 75, 2, 8), ("medium", 128, 96, 4, 16), ("grid", 96, 64, 2, 16)])
+def test_entry_nodes_keep_every_hit(renderer, cam, name, w, h, spp, tile):
+    """A primary ray starts below the root's inner child at the node all primary rays of its tile stay under (r1_capi.cpp
+    compute_entries).  Whatever the camera — a lens wider than the lattice's cells, an origin among the small spheres, a view away
+    from the scene, a focal plane closer than the lens radius — the samples are the oracle's to the bit, through the synchronous
+    frame (MODE 1) and through the frames-in-flight kernel (MODE 0, tiles summed in the kernel)."""
+    sc = r1.create_grid_scene(w, h, 48, 36) if name == "grid" else MAKE[name](w, h)  # (grid: the big-scene kernels, pads measured per node)
+    sa = oracle_scene(sc)
+    if ENTRY_CAMERAS[cam] is not None:
+        sa = r1o.SceneArrays(sa.arrays, _look(*ENTRY_CAMERAS[cam][:2], ENTRY_CAMERAS[cam][2], w / h, *ENTRY_CAMERAS[cam][3:]))
+    renderer.set_scene_raw(_as_cscene(sa), _as_ccamera(sa))
+    p = r1.make_params(w, h, spp, 99, tile_w=tile, tile_h=tile, variant=BVH)
+    img, rays, samples = renderer.render_samples(p)
+    oimg, orays, osamples = r1o.render_frame(sa, oparams(p), want_samples=True)
+    assert rays == orays
+    assert samples.tobytes() == osamples.tobytes()
+    assert img.tobytes() == oimg.tobytes()
+    hf = binding.HostFrame(w, h)
+    renderer.render_async(p, hf)
+    renderer.sync()
+    assert hf.rays == orays and hf.image.tobytes() == oimg.tobytes()
+    hf.close()
