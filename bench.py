@@ -254,7 +254,10 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-table", action="store_true",
                     help="also time the reference's step13 (all threads / 1 thread) on the three scenes and the step1 port "
                          "on the host cores (cpu_baseline.table; adds ~30 s)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.lib:
+        args.lib = os.path.abspath(args.lib)  # (resolved where the command was given)
+    return args
 
 
 def self_launch(args):

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <new>
 #include <utility>
+#include <functional>
 #include <vector>
 
 #include "../../include/rays1.h"
@@ -153,6 +154,9 @@ struct r1_context
     // per-tile entry nodes for primary rays (R1_ENTRY): the tree's nodes on the host, the device table, what it was computed for
     std::vector<float> bvh_nodes_host;
     DevBuf bvh_entry;
+    DevBuf bvh_wide; // R1_BVH4: the collapsed table (small scenes)
+    uint32_t bvh_wide_f4 = 0;
+    int bvh_wide_stack = 0;
     r1_params entry_key;
     int entry_frames = 0;
     bool entry_valid = false;
@@ -268,7 +272,7 @@ extern "C" void r1_destroy(r1_context *c)
     release(c->sweep), release(c->exact), release(c->shade), release(c->mat), release(c->members);
     release(c->bvh_nodes), release(c->bvh_prims), release(c->bvh_ids);
     release(c->wf_paths), release(c->wf_hits), release(c->wf_queue), release(c->wf_counts);
-    release(c->bvh_entry), release(c->land_spill), release(c->gstack), release(c->counters), release(c->samples), release(c->image), release(c->batch_rays);
+    release(c->bvh_wide), release(c->bvh_entry), release(c->land_spill), release(c->gstack), release(c->counters), release(c->samples), release(c->image), release(c->batch_rays);
     release(c->wave_log);
     if (c->host_word)
         (void)hipHostFree(c->host_word);
@@ -439,6 +443,117 @@ struct Landing;
 static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int block_layout, void *d_rays, hipStream_t st, bool throughput_mode,
                          const Batch *batch = nullptr, Landing *landing = nullptr);
 
+// ---- 4-wide nodes (R1_BVH4) -------------------------------------------------------------------------------------
+// The binary tree of a small scene collapsed: a wide node starts as a binary node's two children and replaces its inner child with the
+// largest box by that child's own two children until it holds four (or only leaves).  Boxes and leaves are the binary tree's, so the
+// spheres offered to a ray — and with them every pixel — stay the same; only the number of dependent trips of the walk changes.
+// Table: slot 0 = the binary root (4 float4 as r1_bvh.cpp writes them, child references in the 16-bit form, + 3 float4 of padding: the
+// root step of bvh_advance reads it), then wide node i >= 1 at float4 7 i: children 0, 1 and children 2, 3 as two row triples of the binary
+// form ({m0x m1x m0y m1y} {m0z m1z e0x e1x} {e0y e1y e0z e1z}), then {ref[4]};
+// an empty slot has e = -inf (never passes) and the reference of a leaf without pairs.  Returns the most entries a lane's stack can hold.
+static int build_wide(const std::vector<float> &bin, int root_leaf, std::vector<float> &out)
+{
+    auto ref_of = [&](uint32_t node, int k) { uint32_t v; memcpy(&v, &bin[16 * (size_t)node + 14 + k], 4); return v; };
+    auto ref16 = [](uint32_t ref) { return ((ref >> 16) & 0xF000u) | (ref & 0x0FFFu); };
+    struct Slot { float m[3], e[3]; uint32_t ref; };
+    auto slot_of = [&](uint32_t node, int k) {
+        Slot s;
+        const float *q = &bin[16 * (size_t)node];
+        for (int a = 0; a < 3; ++a)
+            s.m[a] = q[2 * a + k], s.e[a] = q[6 + 2 * a + k];
+        s.ref = ref_of(node, k);
+        return s;
+    };
+    const size_t n_bin = bin.size() / 16;
+    // Which grandchildren a wide node takes: the cut of <= 4 slots through the binary subtree that minimises the summed surface area of the
+    // wide nodes below it — the expected number of wide visits of a random ray, the measure the binary tree was built by.  (Taking the
+    // largest child first, top-down, leaves the bottom level of a balanced tree of odd height as two-slot nodes: 85 wide nodes for the
+    // large scene's 128 binary ones instead of 43.)  <= 8 cuts per node, memoised over <= 256 nodes.
+    std::vector<double> cost(n_bin, -1.0);
+    std::vector<std::vector<Slot>> cut_of(n_bin);
+    auto area_of = [](const Slot &q) { return std::isfinite(q.e[0] + q.e[1] + q.e[2]) ? (double)q.e[0] * q.e[1] + (double)q.e[1] * q.e[2] + (double)q.e[2] * q.e[0] : 0.0; };
+    std::function<double(uint32_t)> solve = [&](uint32_t b) -> double {
+        if (cost[b] >= 0.0)
+            return cost[b];
+        std::vector<std::vector<Slot>> cuts = {{slot_of(b, 0), slot_of(b, 1)}};
+        for (size_t i = 0; i < cuts.size(); ++i)
+            if (cuts[i].size() < 4)
+                for (size_t k = 0; k < cuts[i].size(); ++k)
+                    if (!(cuts[i][k].ref & 0x80000000u))
+                    {
+                        std::vector<Slot> c = cuts[i];
+                        const uint32_t x = c[k].ref;
+                        c[k] = slot_of(x, 0);
+                        c.push_back(slot_of(x, 1));
+                        cuts.push_back(c);
+                    }
+        double best = 1e300;
+        size_t pick = 0;
+        for (size_t i = 0; i < cuts.size(); ++i)
+        {
+            double sum = 0;
+            for (const Slot &q : cuts[i])
+                if (!(q.ref & 0x80000000u))
+                    sum += area_of(q) + solve(q.ref);
+            if (sum < best)
+                best = sum, pick = i;
+        }
+        cut_of[b] = cuts[pick];
+        return cost[b] = best;
+    };
+    std::vector<uint32_t> wide_of(n_bin, 0u), order; // binary inner node -> wide index (0: none yet)
+    auto wide_index = [&](uint32_t b) {
+        if (!wide_of[b])
+            order.push_back(b), wide_of[b] = (uint32_t)order.size();
+        return wide_of[b];
+    };
+    out.assign(28, 0.0f);
+    memcpy(out.data(), bin.data(), 64);
+    // the walk starts at the root's inner child (root step) — or, a tree without that shape, at the root itself
+    const uint32_t start = root_leaf ? ref_of(0, root_leaf == 1 ? 1 : 0) : 0u;
+    std::vector<int> above; // stack entries the ancestors of wide node i can leave
+    int need = 0;
+    if (!(start & 0x80000000u))
+        wide_index(start), above.push_back(0);
+    for (size_t i = 0; i < order.size(); ++i)
+    {
+        solve(order[i]);
+        const std::vector<Slot> slots = cut_of[order[i]];
+        const int here = above[i] + (int)slots.size() - 1;
+        need = std::max(need, here);
+        float w[28];
+        for (int k = 0; k < 4; ++k)
+        {
+            const bool used = k < (int)slots.size();
+            const int base = 12 * (k >> 1), j = k & 1; // children 0, 1 / 2, 3: one binary-form row triple each
+            for (int a = 0; a < 3; ++a)
+                w[base + 2 * a + j] = used ? slots[k].m[a] : 0.0f, w[base + 6 + 2 * a + j] = used ? slots[k].e[a] : -INFINITY;
+            uint32_t r = 0x8000u; // (an empty slot never passes — e = -inf — and if it did, it is a leaf of no pairs)
+            if (used)
+            {
+                if (slots[k].ref & 0x80000000u)
+                    r = ref16(slots[k].ref);
+                else
+                {
+                    const size_t before = order.size();
+                    r = wide_index(slots[k].ref);
+                    if (order.size() != before)
+                        above.push_back(here);
+                }
+            }
+            memcpy(&w[24 + k], &r, 4);
+        }
+        out.insert(out.end(), w, w + 28);
+    }
+    // slot 0's child references in the kernel's form: leaves as r1_ref16, the inner child as its wide index
+    for (int k = 0; k < 2; ++k)
+    {
+        const uint32_t r = ref_of(0, k), r16 = (r & 0x80000000u) ? ref16(r) : wide_of[r];
+        memcpy(&out[14 + k], &r16, 4);
+    }
+    return std::max(need, 1);
+}
+
 extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *cam)
 {
     if (!c || !s || !cam || !s->center_x || !s->center_y || !s->center_z || !s->radius_sq || !s->inv_radius || !s->mat_type ||
@@ -598,6 +713,23 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
     R1_HIP(hipStreamSynchronize(c->stream)); // the host vectors go out of scope
     c->bvh_nodes_host = bvh.nodes;
     c->entry_valid = false;
+    c->bvh_wide_f4 = 0;
+    if (R1_BVH4 && bvh.nodes.size() >= 16 && bvh.nodes.size() / 16 <= R1_NODES_LDS_MAX && !bvh.pad_local)
+    {
+        std::vector<float> wide;
+        c->bvh_wide_stack = build_wide(bvh.nodes, bvh.root_leaf, wide);
+        if (c->bvh_wide_stack <= R1_BVH_STACK && wide.size() / 4 < 7u * 4096u)
+        {
+            if ((rc = ensure(c->bvh_wide, wide.size() * 4)))
+                return rc;
+            R1_HIP(hipMemcpy(c->bvh_wide.p, wide.data(), wide.size() * 4, hipMemcpyHostToDevice));
+            c->bvh_wide_f4 = (uint32_t)(wide.size() / 4);
+        }
+        static const int print = (int)r1_knob("R1_BVH4_PRINT", 0);
+        if (print)
+            fprintf(stderr, "rays1: 4-wide table: %zu binary nodes -> %zu wide nodes, stack %d entries (binary: %d)\n", bvh.nodes.size() / 16, wide.size() / 28 - 1,
+                    c->bvh_wide_stack, bvh.max_depth);
+    }
     c->n_bvh_nodes = (uint32_t)(bvh.nodes.size() / 16);
     c->n_bvh_leaves = bvh.n_leaves;
     c->bvh_depth = bvh.max_depth;
@@ -1043,10 +1175,20 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     static const int big_top_env = (int)r1_knob("R1_BIG_TOP", R1_BVH_TOP_NODES); // tuning experiments
     // (big scenes: at least node 0 — the walk's root step reads it from the LDS copy, whatever the tuning knob says)
     a.bvh_lds_f4 = !(variant == 4 || variant == 5) ? 0u : (!big ? 4u * c->n_bvh_nodes : 4u * std::min<uint32_t>(c->n_bvh_nodes, (uint32_t)std::max(1, big_top_env)));
+    a.bvh_wide = nullptr;
+    if (R1_BVH4 && (variant == 4 || variant == 5) && !big)
+    {
+        if (!c->bvh_wide_f4)
+        {
+            r1_set_error("this build walks 4-wide nodes (R1_BVH4) and the scene's tree has no such table");
+            return R1_EINVAL;
+        }
+        a.bvh_wide = (const float4 *)c->bvh_wide.p, a.bvh_lds_f4 = c->bvh_wide_f4, a.bvh_depth = c->bvh_wide_stack;
+    }
     const int occ_slot = variant + 8 * big + 16 * mode;
     if (c->occupancy[occ_slot] == 0)
         R1_HIP(r1_trace_occupancy(variant, big, mode,
-                                  (variant == 4 || variant == 5) ? (size_t)a.bvh_depth * R1_BLOCK * (big ? 4 : 2) + (size_t)a.bvh_lds_f4 * 16 + (big ? 0 : R1_ENTRY_LDS_BYTES(R1_ENTRY_LDS_MAX)) : 0,
+                                  (variant == 4 || variant == 5) ? (size_t)a.bvh_depth * R1_BLOCK * (big ? 4 : 2) + (size_t)a.bvh_lds_f4 * 16 + R1_ENTRY_LDS_BYTES(a.entry_lds) : 0,
                                   &c->occupancy[occ_slot]));
     int per_cu = c->occupancy[occ_slot];
     if (per_cu < 1)

@@ -65,6 +65,15 @@
 #define R1_ENTRY_LDS_MAX 2048u // tiles per launch up to which the small-scene kernels keep the entry table in LDS (4 KB)
 #define R1_ENTRY_LDS_BYTES(n) ((((size_t)(n) * 2u) + 15u) & ~(size_t)15u)
 #define R1_ENTRY_MODE(mode) (R1_ENTRY && ((mode) == 0 || (mode) == 3 || (mode) == 1))
+// 4-wide nodes for the small-scene tree kernels: the binary tree collapsed on the host (a node takes
+// its grandchildren until it holds four children), seven float4 per node in the workgroup's LDS table, four box tests per trip, the hits
+// pushed far-to-near.  An A/B build: make tuning EXTRA=-DR1_BVH4=1.
+#ifndef R1_BVH4
+#define R1_BVH4 0
+#endif
+#if R1_BVH4 && R1_ENTRY
+#error "R1_ENTRY's table holds references into the binary tree: not with R1_BVH4"
+#endif
 #ifndef R1_LAND_SYNC
 #define R1_LAND_SYNC 0 // 1: the synchronous frame's kernels (MODE 1) too — measured and not adopted: 1.276 against 1.077 ms on the device (the tiles a wave owes are summed at ITS exit, i.e. at the end of the frame's critical path; the resolve launch sums all 950 in 26 us with the whole chip), profiles/r04/land_sync_frame.txt
 #endif
@@ -216,6 +225,7 @@ struct R1TraceArgs
     uint32_t *land_cnt;           // [n_frames * n_local_tiles] x R1_LAND_CNT_STRIDE words: samples each tile still lacks; the tracing waves subtract, the wave that
                                   // owes the tile re-arms
     R1LandArgs land;
+    const float4 *bvh_wide;       // R1_BVH4: the 4-wide table the small-scene kernels copy into LDS instead of scene.bvh_nodes (bvh_lds_f4 float4)
     uint32_t entry_lds;           // R1_ENTRY, small-scene kernels, single frames: the workgroups keep the table as 16-bit words in LDS behind their node table (0: read from bvh_entry)
     const uint32_t *bvh_entry;    // R1_ENTRY: [n_frames * n_local_tiles] child reference (the kernel's form) a primary ray of that tile starts at after the root step
     uint32_t coop_lanes;          // small scenes: once the queue is empty, a wave with <= coop_lanes live paths tests each of them

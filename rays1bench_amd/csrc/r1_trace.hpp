@@ -766,6 +766,50 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
             if ((tid & 63) == __ffsll((long long)__ballot(1)) - 1)
                 wstat[2] += 1;
         }
+#if R1_BVH4
+        if (LN)
+        {
+            // a 4-wide node (r1_capi.cpp build_wide): two child PAIRS in the binary node's row form — {m0x m1x m0y m1y} {m0z m1z e0x e1x}
+            // {e0y e1y e0z e1z}, twice — and {ref[4]}.  Four box tests; every hit becomes ONE word — the upper half of its entry distance
+            // (clamped at 0: the bits of a float >= 0 order as integers) over its 16-bit reference, all ones for a miss — the four words
+            // are sorted (5 min / max pairs), the nearest is visited next and the others go on the stack far-to-near.
+            // (the second pair is fetched after the first is tested — the index passes through the asm statement together with the first
+            //  pair's words: 24 live node floats at once do not fit the 72 registers of the 7-wave build)
+            uint32_t at = 7u * cur;
+            const uint4 rf = *(const uint4 *)(lnodes + at + 6u);
+            float t0, t1, t2, t3;
+            float4 q0 = lnodes[at + 0u], q1 = lnodes[at + 1u], q2 = lnodes[at + 2u];
+            const bool g0 = bvh_box(q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, pa_ray, oi, inv, ainv, best, t0);
+            const bool g1 = bvh_box(q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, pa_ray, oi, inv, ainv, best, t1);
+            uint32_t k0 = g0 ? ((__float_as_uint(fmaxf(t0, 0.0f)) & 0xFFFF0000u) | rf.x) : 0xFFFFFFFFu;
+            uint32_t k1 = g1 ? ((__float_as_uint(fmaxf(t1, 0.0f)) & 0xFFFF0000u) | rf.y) : 0xFFFFFFFFu;
+            asm volatile("" : "+v"(at), "+v"(k0), "+v"(k1));
+            q0 = lnodes[at + 3u], q1 = lnodes[at + 4u], q2 = lnodes[at + 5u];
+            const bool g2 = bvh_box(q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, pa_ray, oi, inv, ainv, best, t2);
+            const bool g3 = bvh_box(q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, pa_ray, oi, inv, ainv, best, t3);
+            uint32_t k2 = g2 ? ((__float_as_uint(fmaxf(t2, 0.0f)) & 0xFFFF0000u) | rf.z) : 0xFFFFFFFFu;
+            uint32_t k3 = g3 ? ((__float_as_uint(fmaxf(t3, 0.0f)) & 0xFFFF0000u) | rf.w) : 0xFFFFFFFFu;
+            uint32_t lo, hi;
+            lo = min(k0, k1), hi = max(k0, k1), k0 = lo, k1 = hi;
+            lo = min(k2, k3), hi = max(k2, k3), k2 = lo, k3 = hi;
+            lo = min(k0, k2), hi = max(k0, k2), k0 = lo, k2 = hi;
+            lo = min(k1, k3), hi = max(k1, k3), k1 = lo, k3 = hi;
+            lo = min(k1, k2), hi = max(k1, k2), k1 = lo, k2 = hi;
+            if (k3 != 0xFFFFFFFFu)
+                trav_put(trav, sp * R1_BLOCK + tid, k3 & 0xFFFFu), ++sp;
+            if (k2 != 0xFFFFFFFFu)
+                trav_put(trav, sp * R1_BLOCK + tid, k2 & 0xFFFFu), ++sp;
+            if (k1 != 0xFFFFFFFFu)
+                trav_put(trav, sp * R1_BLOCK + tid, k1 & 0xFFFFu), ++sp;
+            if (k0 != 0xFFFFFFFFu)
+                cur = k0 & 0xFFFFu;
+            else if (sp > 0)
+                cur = trav_get(trav, --sp * R1_BLOCK + tid);
+            else
+                cur = R1_BVH_DONE;
+            return;
+        }
+#endif
         // {m0x m1x m0y m1y} {m0z m1z e0x e1x} {e0y e1y e0z e1z} {A K child0 child1}
         float4 q0, q1, q2, q3;
         if (LN || cur < top)
@@ -862,6 +906,10 @@ __device__ __forceinline__ void bvh_advance(const R1DeviceScene &S, const V3 o, 
         // (the sibling's own visit taken into this step as well — `if (cur < LEAF_BIT) visit_node();` here — measured 35.5 against 36.2
         //  Grays/s: a generic visit runs at 0.54 lane utilisation inside the loop and at the ~0.34 of the starting lanes out here)
     }
+#if R1_BVH4
+    if (LN && cur == 0u)
+        cur = 1u; // a tree without the root step: slot 0 of the 4-wide table is the binary root for the root step's use, the collapsed root is node 1
+#endif
     for (;;)
     {
         const unsigned long long walking = __ballot(cur != R1_BVH_DONE);
@@ -1609,8 +1657,8 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
         float4 *dst = (float4 *)(s_trav + trav_words);
         for (uint32_t i = (uint32_t)tid; i < A.bvh_lds_f4; i += R1_BLOCK)
         {
-            float4 q = A.scene.bvh_nodes[i];
-            if (LN && (i & 3u) == 3u) // {A K child0 child1}: the small-scene kernels walk with 16-bit child references
+            float4 q = (R1_BVH4 && LN) ? A.bvh_wide[i] : A.scene.bvh_nodes[i]; // (4-wide table: references already in the 16-bit form)
+            if (LN && !R1_BVH4 && (i & 3u) == 3u) // {A K child0 child1}: the small-scene kernels walk with 16-bit child references
                 q.z = __uint_as_float(r1_ref16(__float_as_uint(q.z))), q.w = __uint_as_float(r1_ref16(__float_as_uint(q.w)));
             dst[i] = q;
         }
