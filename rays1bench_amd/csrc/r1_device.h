@@ -57,8 +57,9 @@
 // its 32 x 32 tile stay under (computed on the host per camera and tiling, r1_capi.cpp compute_entries); 0: every walk starts at that child.
 // Built, bit-identical, measured and NOT adopted (round 4): 9 % fewer node visits per ray (5.41 -> 4.91 on large 1200x800x10; 42 % of the
 // tiles' primary rays are done after the root step) but 5 % more wave iterations — the primary rays' shorter walks do not shorten the LONGEST
-// walk of a wave, which sets the trips of the divergent loops — and the same Grays/s on every BASELINE configuration within the run-to-run
-// noise (profiles/r04/entry_nodes_ab.txt).  `make tuning EXTRA=-DR1_ENTRY=1` builds it; tools/entry_ab.sh runs the parity tests and the A/B.
+// walk of a wave, which sets the trips of the divergent loops — and 8 % (table in global memory: a vector-memory wait in the root step) to 12 %
+// (table in LDS: six workgroups per CU instead of seven) FEWER Grays/s (profiles/r04/entry_nodes_ab.txt).
+// `make tuning EXTRA=-DR1_ENTRY=1` builds it; tools/entry_ab.sh runs the parity tests, tools/walk_ab*.sh the A/B.
 #ifndef R1_ENTRY
 #define R1_ENTRY 0
 #endif
