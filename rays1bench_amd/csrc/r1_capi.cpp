@@ -101,7 +101,7 @@ struct r1_context
     bool ring_on = false;
 
     // scene
-    DevBuf sweep, exact, shade, mat, members;
+    DevBuf sweep, exact, exact_g, shade, mat, members;
     DevBuf bvh_nodes, bvh_prims, bvh_ids; // R1_VARIANT_BVH (r1_bvh.cpp)
     DevBuf wf_paths, wf_hits, wf_queue, wf_counts; // R1_VARIANT_WAVEFRONT workspace
     DevBuf wave_log;                               // STATS builds: per-wave {start, queue empty, end, iterations}
@@ -269,7 +269,7 @@ extern "C" void r1_destroy(r1_context *c)
     (void)hipSetDevice(c->device);
     if (c->stream)
         (void)hipStreamSynchronize(c->stream);
-    release(c->sweep), release(c->exact), release(c->shade), release(c->mat), release(c->members);
+    release(c->sweep), release(c->exact), release(c->exact_g), release(c->shade), release(c->mat), release(c->members);
     release(c->bvh_nodes), release(c->bvh_prims), release(c->bvh_ids);
     release(c->wf_paths), release(c->wf_hits), release(c->wf_queue), release(c->wf_counts);
     release(c->bvh_wide), release(c->bvh_entry), release(c->land_spill), release(c->gstack), release(c->counters), release(c->samples), release(c->image), release(c->batch_rays);
@@ -668,6 +668,15 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
         mat[4 * a + 3] = type == R1_MAT_DIELECTRIC ? r0 : 0.0f;
     }
 
+    // the members' spheres once more, in group order (exact_trips fetches sphere and index side by side)
+    std::vector<float> exact_g(4 * (size_t)R1_GROUP_MAX * ns_alloc);
+    for (size_t k = 0; k < (size_t)R1_GROUP_MAX * ns_alloc; ++k)
+    {
+        const uint32_t a = members[k];
+        for (int q = 0; q < 4; ++q)
+            exact_g[4 * k + q] = a != 0xFFFFFFFFu ? exact[4 * (size_t)a + q] : (q == 3 ? -INFINITY : 0.0f);
+    }
+
     // the optional spatial index over the same active spheres (R1_VARIANT_BVH)
     R1Bvh bvh;
     {
@@ -695,7 +704,7 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
         return rc;
     if ((rc = ensure(c->sweep, sweep.size() * 4)) || (rc = ensure(c->exact, exact.size() * 4)) ||
         (rc = ensure(c->shade, shade.size() * 4)) || (rc = ensure(c->mat, mat.size() * 4)) ||
-        (rc = ensure(c->members, members.size() * 4)))
+        (rc = ensure(c->members, members.size() * 4)) || (rc = ensure(c->exact_g, exact_g.size() * 4)))
         return rc;
     // Uploads go through the context's OWN stream (then one wait): librays1 never touches the null stream.  A process
     // that keeps K frames in flight on K contexts with GPU_MAX_HW_QUEUES = K would otherwise hand one of its K hardware
@@ -707,6 +716,7 @@ extern "C" int r1_set_scene(r1_context *c, const r1_scene *s, const r1_camera *c
     R1_HIP(hipMemcpyAsync(c->shade.p, shade.data(), shade.size() * 4, hipMemcpyHostToDevice, c->stream));
     R1_HIP(hipMemcpyAsync(c->mat.p, mat.data(), mat.size() * 4, hipMemcpyHostToDevice, c->stream));
     R1_HIP(hipMemcpyAsync(c->members.p, members.data(), members.size() * 4, hipMemcpyHostToDevice, c->stream));
+    R1_HIP(hipMemcpyAsync(c->exact_g.p, exact_g.data(), exact_g.size() * 4, hipMemcpyHostToDevice, c->stream));
     R1_HIP(hipMemcpyAsync(c->bvh_nodes.p, bvh.nodes.data(), bvh.nodes.size() * 4, hipMemcpyHostToDevice, c->stream));
     R1_HIP(hipMemcpyAsync(c->bvh_prims.p, bvh.prims.data(), bvh.prims.size() * 4, hipMemcpyHostToDevice, c->stream));
     R1_HIP(hipMemcpyAsync(c->bvh_ids.p, bvh.ids.data(), bvh.ids.size() * 4, hipMemcpyHostToDevice, c->stream));
@@ -1088,6 +1098,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     a.scene.shade = (const float4 *)c->shade.p;
     a.scene.mat = (const float4 *)c->mat.p;
     a.scene.members = (const uint32_t *)c->members.p;
+    a.scene.exact_g = (const float4 *)c->exact_g.p;
     a.scene.n_active = c->n_active;
     a.scene.n_sweep = c->n_sweep;
     a.scene.n_multi = c->n_multi;

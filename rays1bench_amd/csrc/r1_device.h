@@ -69,6 +69,14 @@
 // 4-wide nodes for the small-scene tree kernels: the binary tree collapsed on the host (a node takes
 // its grandchildren until it holds four children), seven float4 per node in the workgroup's LDS table, four box tests per trip, the hits
 // pushed far-to-near.  An A/B build: make tuning EXTRA=-DR1_BVH4=1.
+// exhaustive sweep, exact phase (exact_trips): member spheres from a table in group order (one global fetch in the dependent chain instead
+// of two), and the wave's rays as two 16-byte LDS reads per slot instead of six 4-byte ones
+#ifndef R1_EXACT_G
+#define R1_EXACT_G 1
+#endif
+#ifndef R1_RAYS_AOS
+#define R1_RAYS_AOS 0
+#endif
 #ifndef R1_BVH4
 #define R1_BVH4 0
 #endif
@@ -155,6 +163,8 @@ struct R1DeviceScene
     // {type, param}.
     const float4 *exact;
     const float4 *shade;   // {inv_radius, albedo_r, albedo_g, albedo_b}
+    const float4 *exact_g;   // R1_EXACT_G: the same {cx, cy, cz, radius_sq} in GROUP order, [n_sweep (+pad)][R1_GROUP_MAX] ({0, 0, 0, -inf} = none: never an offer):
+                             // the exact phase fetches a member's sphere and its index side by side instead of one after the other
     const uint32_t *members; // [n_sweep (+pad)][R1_GROUP_MAX] active indices of a group's spheres, 0xFFFFFFFF = none
     const float4 *mat;     // {bit_cast<float>(type), param, 1/ref_idx, ((1-ref)/(1+ref))^2} (last two: dielectrics)
     uint32_t n_multi;      // groups [0, n_multi) have 2..R1_GROUP_MAX members, groups >= n_multi exactly one

@@ -286,12 +286,22 @@ __device__ __forceinline__ void exact_trips(const R1DeviceScene &S, const V3 o, 
         const uint32_t pr = have_pair ? (uint32_t)pairs[j] : ((uint32_t)lane << IDX_BITS);
         const int owner = (int)(pr >> IDX_BITS);
         const uint32_t grp = pr & ((1u << IDX_BITS) - 1u);
-        const uint32_t idx = have_pair ? S.members[(size_t)grp * R1_GROUP_MAX + (SLOTS == 1 ? 0 : (lane & (R1_GROUP_MAX - 1)))] : 0xFFFFFFFFu;
+        const uint32_t slot = grp * R1_GROUP_MAX + (SLOTS == 1 ? 0u : (uint32_t)(lane & (R1_GROUP_MAX - 1)));
+        const uint32_t idx = have_pair ? S.members[slot] : 0xFFFFFFFFu;
+#if R1_EXACT_G
+        const f4 sphere = ((const f4 *)S.exact_g)[slot]; // (no pair: group 0's slots, fetched and not used)
+#endif
         V3 ro, rd;
         if (rays)
         {
+#if R1_RAYS_AOS
+            const float *w = rays + (owner >> 3) * R1_BLOCK + (owner & 7) * 8;
+            const f4 r0 = *(const f4 *)w, r1 = *(const f4 *)(w + 4);
+            ro = mk(r0.x, r0.y, r0.z), rd = mk(r0.w, r1.x, r1.y);
+#else
             ro = mk(rays[0 * R1_BLOCK + owner], rays[1 * R1_BLOCK + owner], rays[2 * R1_BLOCK + owner]);
             rd = mk(rays[3 * R1_BLOCK + owner], rays[4 * R1_BLOCK + owner], rays[5 * R1_BLOCK + owner]);
+#endif
         }
         else
         {
@@ -300,7 +310,11 @@ __device__ __forceinline__ void exact_trips(const R1DeviceScene &S, const V3 o, 
         }
         if (idx != 0xFFFFFFFFu)
         {
+#if R1_EXACT_G
+            const float t = exact_offer(sphere, ro, rd);
+#else
             const float t = exact_offer(((const f4 *)S.exact)[idx], ro, rd);
+#endif
             if (t < FLT_MAX)
                 atomicMin(&best[owner], ((unsigned long long)__float_as_uint(t) << 32) | idx);
         }
@@ -313,8 +327,15 @@ __device__ __forceinline__ const float *publish_rays(uint32_t *scratch /* [>= 6]
 {
     float *t = (float *)scratch;
     __builtin_amdgcn_wave_barrier(); // every lane has read what it needed from the scratch rows
+#if R1_RAYS_AOS
+    // eight words per ray, side by side: the wave's 64 columns of rows 0..7 hold rays 8 r .. 8 r + 7 in row r (ray_at)
+    float *w = t + (tid & ~63) + ((tid & 63) >> 3) * R1_BLOCK + (tid & 7) * 8;
+    *(f4 *)w = f4{o.x, o.y, o.z, d.x};
+    *(f4 *)(w + 4) = f4{d.y, d.z, 0.0f, 0.0f};
+#else
     t[0 * R1_BLOCK + tid] = o.x, t[1 * R1_BLOCK + tid] = o.y, t[2 * R1_BLOCK + tid] = o.z;
     t[3 * R1_BLOCK + tid] = d.x, t[4 * R1_BLOCK + tid] = d.y, t[5 * R1_BLOCK + tid] = d.z;
+#endif
     __builtin_amdgcn_wave_barrier();
     return t + (tid & ~63);
 }
@@ -385,7 +406,7 @@ __device__ __forceinline__ void cooperative_bits(const R1DeviceScene &S, const V
                     pairs[pos_s--] = v;
             }
         }
-        static_assert(R1_BIT_WORDS >= 6, "the ray table needs six rows of the flag words");
+        static_assert(R1_BIT_WORDS >= (R1_RAYS_AOS ? 8 : 6) && R1_CAND_CAP >= 8, "the ray table needs six (eight: side-by-side form) rows of the flag words");
         const float *rays = publish_rays(const_cast<uint32_t *>(words), o, d, tid); // the words of this batch are consumed
         exact_trips<STATS, IDX, R1_GROUP_MAX>(S, o, d, total_m, pairs, best, lane, wstat, rays);
         exact_trips<STATS, IDX, 1>(S, o, d, total_s, pairs + (CAP - total_s), best, lane, wstat, rays);
