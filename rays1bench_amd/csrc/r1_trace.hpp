@@ -69,6 +69,34 @@ typedef float f16 __attribute__((ext_vector_type(16)));
 typedef const f16 __attribute__((address_space(4))) *cf16_ptr;
 typedef uint32_t __attribute__((address_space(1))) r1_gu32; // a word of global memory (explicit: keeps rarely used stores / loads from becoming generic ones)
 
+// The kernel's arguments read again from the kernarg segment (scalar loads, constant cache) at the place of use, through a pointer the
+// optimiser cannot trace back to the prologue's loads.  hipcc keeps every argument field the loop uses in an SGPR from the prologue on;
+// this kernel needs ~190 of them, ~90 live in lanes of two VGPRs, and every use of such a one is a v_readlane — a VALU issue slot, and
+// whole 16-register tuples at a time (the fast-division constants of start_sample alone: ~90 v_readlane per loop iteration, 478 in the
+// kernel).  A field read through R1_FRESH_ARGS is an s_load where it is used and occupies an SGPR only there.
+#ifndef R1_FRESH
+#define R1_FRESH 1
+#endif
+typedef const __attribute__((address_space(4))) uint32_t *r1_kargs_ptr;
+union R1ArgWords
+{
+    R1TraceArgs a;
+    uint32_t w[sizeof(R1TraceArgs) / 4];
+    __device__ R1ArgWords() {}
+};
+__device__ __forceinline__ void fresh_args(R1ArgWords &u)
+{
+    r1_kargs_ptr k = (r1_kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr(); // (the kernel's one argument starts the segment)
+    asm volatile("" : "+s"(k));
+#pragma unroll
+    for (uint32_t i = 0; i < sizeof(R1TraceArgs) / 4; ++i)
+        u.w[i] = k[i]; // (only the words that are used afterwards are fetched)
+}
+#define R1_FRESH_ARGS(L)                                                                                                                  \
+    R1ArgWords L##_words;                                                                                                                 \
+    fresh_args(L##_words);                                                                                                                \
+    const R1TraceArgs &L = L##_words.a;
+
 // Correctly rounded sqrt / division.  NOT __fsqrt_rn/__fdiv_rn: without
 // OCML_BASIC_ROUNDED_OPERATIONS hipcc maps __fsqrt_rn to the approximate v_sqrt_f32.  Plain
 // sqrtf() and `/` are IEEE under -fhip-fp32-correctly-rounded-divide-sqrt (set in the Makefile).
@@ -1865,13 +1893,18 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
             }
             const uint32_t avail = q_end - q_next;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+#if R1_FRESH
+            R1_FRESH_ARGS(FA) // (what start_sample reads: tiling, fast divisions, camera — fetched here, not carried around the loop)
+#else
+            const R1TraceArgs &FA = A;
+#endif
             // (Generating the primary rays in a separate full-width kernel and loading them here was
             // measured: 1.52 ms per frame against 1.28 — the extra launch per frame costs more overlap
             // between frames than the refill saves.)
             if (SPARE)
             {
                 if (!has_spare && rank < avail)
-                    has_spare = start_sample<BATCH>(A, spare, q_next + rank); // false: void slot, ask again
+                    has_spare = start_sample<BATCH>(FA, spare, q_next + rank); // false: void slot, ask again
             }
             else if (!alive && rank < avail)
             {
@@ -1882,7 +1915,7 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
                         start_ray(A, p, (int)(px.xy & 0xFFFFu), (int)(px.xy >> 16), 0u, A.seed);
                 }
                 else
-                    alive = start_sample<BATCH>(A, p, q_next + rank); // false: void slot, ask again
+                    alive = start_sample<BATCH>(FA, p, q_next + rank); // false: void slot, ask again
                 if (VARIANT == 4 && alive)
                     trav_start(tv);
             }
