@@ -84,6 +84,14 @@ union R1ArgWords
     uint32_t w[sizeof(R1TraceArgs) / 4];
     __device__ R1ArgWords() {}
 };
+// (a pointer that arrives as two loaded words is a generic pointer to the optimiser — flat loads.  The kernel's pointer arguments all
+//  point to global memory: they are fetched as what they are, pointers into address space 1, the way clang passes them to a kernel)
+template <typename T>
+__device__ __forceinline__ T *global_ptr_at(r1_kargs_ptr k, const size_t offset)
+{
+    typedef __attribute__((address_space(1))) T *gptr;
+    return (T *)*(const __attribute__((address_space(4))) gptr *)((const __attribute__((address_space(4))) char *)k + offset);
+}
 __device__ __forceinline__ void fresh_args(R1ArgWords &u)
 {
     r1_kargs_ptr k = (r1_kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr(); // (the kernel's one argument starts the segment)
@@ -91,6 +99,11 @@ __device__ __forceinline__ void fresh_args(R1ArgWords &u)
 #pragma unroll
     for (uint32_t i = 0; i < sizeof(R1TraceArgs) / 4; ++i)
         u.w[i] = k[i]; // (only the words that are used afterwards are fetched)
+#define R1_G(f) u.a.f = global_ptr_at<__typeof__(*u.a.f)>(k, __builtin_offsetof(R1TraceArgs, f));
+    R1_G(scene.sweep) R1_G(scene.exact) R1_G(scene.shade) R1_G(scene.exact_g) R1_G(scene.members) R1_G(scene.mat) R1_G(scene.bvh_nodes) R1_G(scene.bvh_prims)
+    R1_G(scene.bvh_ids) R1_G(queue) R1_G(samples) R1_G(num_rays) R1_G(gstack) R1_G(stats) R1_G(land_cnt) R1_G(land.out) R1_G(land.rays_dst)
+    R1_G(land.frame_rays) R1_G(land.frame_left) R1_G(land.clear_heads) R1_G(land.owed_spill) R1_G(land.error) R1_G(bvh_wide) R1_G(bvh_entry)
+#undef R1_G
 }
 #define R1_FRESH_ARGS(L)                                                                                                                  \
     R1ArgWords L##_words;                                                                                                                 \
@@ -1894,7 +1907,11 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
             const uint32_t avail = q_end - q_next;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
 #if R1_FRESH
-            R1_FRESH_ARGS(FA) // (what start_sample reads: tiling, fast divisions, camera — fetched here, not carried around the loop)
+            // (what start_sample reads: tiling, fast divisions, camera — fetched here, not carried around the loop)
+            R1ArgWords FA_words;
+            if (!PIX)
+                fresh_args(FA_words);
+            const R1TraceArgs &FA = PIX ? A : FA_words.a;
 #else
             const R1TraceArgs &FA = A;
 #endif
@@ -1978,16 +1995,31 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
         {
             // while-while with carry-over
             constexpr bool ENTRY = R1_ENTRY_MODE(MODE);
+#if R1_FRESH
+            R1_FRESH_ARGS(HA) // (table pointers, the tree's centre: fetched for the walk, free again after it)
+#else
+            const R1TraceArgs &HA = A;
+#endif
             // (a primary ray that starts its walk: depth 0 and at the root)
-            const uint32_t entry_idx = ENTRY && p.depth == 0 && tv.cur == 0u ? fastdiv(p.k, A.div_full) : 0xFFFFFFFFu;
-            bvh_advance<STATS, true, LN, TS, ENTRY>(A.scene, p.o, p.d, tv, (TS *)s_trav, tid, (uint32_t)__popcll(live_now), wstat, lnodes, top, A.bvh_entry, entry_idx,
-                                                    (LN && !BATCH && A.entry_lds) ? (const uint16_t *)(lnodes + A.bvh_lds_f4) : nullptr);
+            const uint32_t entry_idx = ENTRY && p.depth == 0 && tv.cur == 0u ? fastdiv(p.k, HA.div_full) : 0xFFFFFFFFu;
+            bvh_advance<STATS, true, LN, TS, ENTRY>(HA.scene, p.o, p.d, tv, (TS *)s_trav, tid, (uint32_t)__popcll(live_now), wstat, lnodes, top, HA.bvh_entry, entry_idx,
+                                                    (LN && !BATCH && HA.entry_lds) ? (const uint16_t *)(lnodes + HA.bvh_lds_f4) : nullptr);
             ready = alive && tv.cur == R1_BVH_DONE;
             if (tv.best_id != 0xFFFFFFFFu)
                 t_hit = tv.best, hit = (int)tv.best_id;
         }
         else
-            sweep_prefilter<STATS, IDX, BIG>(A.scene, alive, p.o, p.d, t_hit, hit, s_cand, s_pairs, s_best, s_tile, tid, wstat);
+        {
+#if R1_FRESH
+            R1ArgWords HA_words;
+            if (!PIX)
+                fresh_args(HA_words);
+            const R1TraceArgs &HA = PIX ? A : HA_words.a;
+#else
+            const R1TraceArgs &HA = A;
+#endif
+            sweep_prefilter<STATS, IDX, BIG>(HA.scene, alive, p.o, p.d, t_hit, hit, s_cand, s_pairs, s_best, s_tile, tid, wstat);
+        }
         if (STATS)
         {
             wstat[6] += __builtin_readcyclecounter() - wstat[15];
@@ -1995,21 +2027,31 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
         }
 
         bool fin = false; // this lane's sample ended in this iteration
+#if R1_FRESH
+        // (material tables, the stack workspace, where the records go; PIXEL mode keeps the prologue's copy: its pixel_write indexes the
+        //  arguments in a way that leaves the fresh copy in scratch)
+        R1ArgWords SA_words;
+        if (!PIX)
+            fresh_args(SA_words);
+        const R1TraceArgs &SA = PIX ? A : SA_words.a;
+#else
+        const R1TraceArgs &SA = A;
+#endif
         if (ready)
         {
             V3 col;
-            if (shade_level<BIG, LW>(A, p, hit, t_hit, s_stack, gstride, gtid, tid, col))
+            if (shade_level<BIG, LW>(SA, p, hit, t_hit, s_stack, gstride, gtid, tid, col))
             {
                 if (PIX)
                 {
                     px.acc = vadd(px.acc, col); // col += color(...), samples in order (rayweek1.cpp:762)
-                    if (++px.s == (uint32_t)A.spp)
-                        pixel_write(A, px);
+                    if (++px.s == (uint32_t)SA.spp)
+                        pixel_write(SA, px);
                 }
                 else if (LAND)
-                    A.samples[p.k] = make_float4(col.x, col.y, col.z, __uint_as_float(path_rays(p) | A.land_tag));
+                    SA.samples[p.k] = make_float4(col.x, col.y, col.z, __uint_as_float(path_rays(p) | SA.land_tag));
                 else
-                    A.samples[p.k] = make_float4(col.x, col.y, col.z, __uint_as_float(path_rays(p)));
+                    SA.samples[p.k] = make_float4(col.x, col.y, col.z, __uint_as_float(path_rays(p)));
                 if (!LAND)
                     lane_rays += path_rays(p); // (LAND: the waves that sum the tiles add up the records' counts)
                 alive = false, fin = true;
@@ -2018,7 +2060,7 @@ __global__ void __launch_bounds__(R1_BLOCK, (TraceWaves<VARIANT, STATS, BIG, MOD
                 trav_start(tv); // the scattered ray starts its walk at the root
         }
         if (LAND && fin)
-            land_count(A, row, p.k);
+            land_count(SA, row, p.k);
         if (STATS)
             wstat[7] += __builtin_readcyclecounter() - wstat[15];
     }
