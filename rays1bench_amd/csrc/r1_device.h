@@ -77,6 +77,9 @@
 #ifndef R1_RAYS_AOS
 #define R1_RAYS_AOS 0
 #endif
+#ifndef R1_SWEEP_PAIRS2
+#define R1_SWEEP_PAIRS2 1 // exhaustive sweep, group test: two pairs of groups interleaved (sweep_prefilter)
+#endif
 #ifndef R1_BVH4
 #define R1_BVH4 0
 #endif

@@ -560,7 +560,28 @@ __device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const bo
         const v2f r = q - kp;                                                                                          \
         R1_FLAG(r.x) R1_FLAG(r.y)                                                                                      \
     }
+#if R1_SWEEP_PAIRS2
+        // two pairs of groups side by side, statement by statement: the chains of one pair fill the wait states hipcc otherwise pads the
+        // other's dependent v_pk_fma_f32 with (two s_nop per pair in the one-pair form)
+#define R1_PAIR2_BITS(LA, BA, LB, BB)                                                                                  \
+    {                                                                                                                  \
+        const v2f cxa = {LA[BA + 0], LA[BA + 1]}, cya = {LA[BA + 2], LA[BA + 3]}, cza = {LA[BA + 4], LA[BA + 5]};      \
+        const v2f cxb = {LB[BB + 0], LB[BB + 1]}, cyb = {LB[BB + 2], LB[BB + 3]}, czb = {LB[BB + 4], LB[BB + 5]};      \
+        v2f nba = __builtin_elementwise_fma(cxa, dxx, nod), nbb = __builtin_elementwise_fma(cxb, dxx, nod);            \
+        v2f ta = __builtin_elementwise_fma(cxa, mxx, ooa), tb = __builtin_elementwise_fma(cxb, mxx, ooa);              \
+        nba = __builtin_elementwise_fma(cya, dyy, nba), nbb = __builtin_elementwise_fma(cyb, dyy, nbb);                \
+        ta = __builtin_elementwise_fma(cya, myy, ta), tb = __builtin_elementwise_fma(cyb, myy, tb);                    \
+        nba = __builtin_elementwise_fma(cza, dzz, nba), nbb = __builtin_elementwise_fma(czb, dzz, nbb);                \
+        ta = __builtin_elementwise_fma(cza, mzz, ta), tb = __builtin_elementwise_fma(czb, mzz, tb);                    \
+        const v2f qa = __builtin_elementwise_fma(nba, nba, -ta), qb = __builtin_elementwise_fma(nbb, nbb, -tb);        \
+        const v2f kpa = {LA[BA + 6], LA[BA + 7]}, kpb = {LB[BB + 6], LB[BB + 7]};                                      \
+        const v2f ra = qa - kpa, rb = qb - kpb;                                                                        \
+        R1_FLAG(ra.x) R1_FLAG(ra.y) R1_FLAG(rb.x) R1_FLAG(rb.y)                                                        \
+    }
+#define R1_CHUNK_BITS(L0, L1) {R1_PAIR2_BITS(L0, 0, L0, 8) R1_PAIR2_BITS(L1, 0, L1, 8)}
+#else
 #define R1_CHUNK_BITS(L0, L1) {R1_PAIR_BITS(L0, 0) R1_PAIR_BITS(L0, 8) R1_PAIR_BITS(L1, 0) R1_PAIR_BITS(L1, 8)}
+#endif
         uint32_t bits = 0;
         uint32_t nwords = 0, gbase = 0; // wave-uniform
         // two register sets (A, B) alternate: while one chunk is evaluated the next one loads
@@ -608,6 +629,7 @@ __device__ __forceinline__ void sweep_prefilter(const R1DeviceScene &S, const bo
         cooperative_bits<STATS, IDX>(S, o, d, nwords, gbase, cand, wpairs, wbest, tid, lane, wstat);
 #undef R1_CHUNK_BITS
 #undef R1_PAIR_BITS
+#undef R1_PAIR2_BITS
 #undef R1_FLAG
     }
     else
