@@ -49,7 +49,7 @@ def kernels_of(co):
         if m:
             cur = m.group(1) if m.group(1) in meta else None
             if cur:
-                meta[cur].update({"flat_load": 0, "flat_store": 0, "scratch_insts": 0, "v_mfma": 0, "insts": 0})
+                meta[cur].update({"flat_load": 0, "flat_store": 0, "scratch_insts": 0, "v_mfma": 0, "insts": 0, "lane_moves": 0})
             continue
         if cur:
             t = line.split()
@@ -65,6 +65,8 @@ def kernels_of(co):
                 meta[cur]["scratch_insts"] += 1
             elif op.startswith("v_mfma"):
                 meta[cur]["v_mfma"] += 1
+            elif op in ("v_readlane_b32", "v_writelane_b32"):  # SGPR spill traffic: each one is a VALU issue slot
+                meta[cur]["lane_moves"] += 1
     return meta
 
 
@@ -86,9 +88,9 @@ def main():
     for name in sorted(k):
         m = k[name]
         short = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip().replace("(R1TraceArgs)", "")[:58]
-        print("%-58s vgpr %3s sgpr %3s vspill %3s sspill %3s lds %6s scratch %4s flat_ld %3s scratch_i %3s mfma %s" % (
+        print("%-58s vgpr %3s sgpr %3s vspill %3s sspill %3s lds %6s scratch %4s flat_ld %3s scratch_i %3s mfma %s lane_moves %s" % (
             short, m["vgpr"], m["sgpr"], m["vgpr_spill"], m["sgpr_spill"], m["lds"], m["scratch"], m.get("flat_load", "?"),
-            m.get("scratch_insts", "?"), m.get("v_mfma", "?")))
+            m.get("scratch_insts", "?"), m.get("v_mfma", "?"), m.get("lane_moves", "?")))
 
 
 if __name__ == "__main__":
