@@ -1223,7 +1223,7 @@ static int enqueue_frame(r1_context *c, const r1_params *p, void *d_out, int blo
     {
         // few, long-lived workgroups per frame (>= R1_SAMPLES_PER_LANE samples per lane), but not fewer
         // than R1_MIN_BLOCKS while that still leaves R1_SAMPLES_PER_LANE_MIN samples per lane
-        const long long spl = spl_env > 0 ? spl_env : 1;
+        const long long spl = p->num_shards > 1 ? R1_SAMPLES_PER_LANE_SHARD : (spl_env > 0 ? spl_env : 1);
         const long long hi = ((long long)c->total_samples + R1_BLOCK * spl - 1) / (R1_BLOCK * spl);
         const long long lo = ((long long)c->total_samples + R1_BLOCK * R1_SAMPLES_PER_LANE_MIN - 1) / (R1_BLOCK * R1_SAMPLES_PER_LANE_MIN);
         needed = std::max(hi, std::min(minb_env, lo));

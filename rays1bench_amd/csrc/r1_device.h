@@ -28,10 +28,13 @@
 #define R1_GROUP_MAX 4         // spheres per group (level 1 of the sweep tests group bounds)
 #define R1_GROUP_MIN_SPHERES 128 // scenes with fewer active spheres are swept ungrouped
 #define R1_GROUP_RATIO 3.5     // a group's bounding radius stays within this factor of its smallest member radius
-#define R1_SAMPLES_PER_LANE 100    // throughput mode grid sizing: samples each lane should get (see enqueue_frame): 1200x800x10 -> 380
-                                   // workgroups per frame (round 4, tiles summed in the kernel: 150 / 100 / 80 samples = 254 / 380 / 475 workgroups:
-                                   // 35.4 / 35.2 / 34.3 Grays/s over 300 steps, 32.1 / 33.0 / 32.8 over the driver's 20 — a burst drains better
-                                   // with more, shorter-lived workgroups per frame, a long run loses ~1 % to their drains; round 3 ran 150) ...
+#define R1_SAMPLES_PER_LANE 125    // throughput mode grid sizing: samples each lane should get (see enqueue_frame): 1200x800x10 -> 300
+                                   // workgroups per frame.  Re-tuned after DESIGN §4.13 (a cheaper refill shifts the balance towards fewer,
+                                   // longer-lived workgroups; tools/spl_sweep2.sh, three alternating rounds): 100 / 115 / 125 / 135 / 150 samples
+                                   // -> 36.46 / 36.75 / 36.90 / 37.00 / 37.3 Grays/s over 300 steps and 32.7 / 33.3 / 33.4 / 32.7 / 32.0 over the
+                                   // driver's 20 (a burst drains better with more, shorter-lived workgroups; a long run loses to their drains) ...
+#define R1_SAMPLES_PER_LANE_SHARD 100 // ... a rank's share of a frame (num_shards > 1) keeps 100: 0.1054 against 0.1069 ms per frame for an
+                                   // emulated rank of eight ...
 #define R1_MIN_BLOCKS 128          // ... but at least this many workgroups per frame (the per-rank frames of a 4- or 8-GPU run:
                                    // 0.301 ms per frame against 0.329 with 256) ...
 #define R1_SAMPLES_PER_LANE_MIN 32 // ... as long as a lane still gets this many samples
