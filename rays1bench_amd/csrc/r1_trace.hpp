@@ -78,6 +78,7 @@ typedef uint32_t __attribute__((address_space(1))) r1_gu32; // a word of global 
 #define R1_FRESH 1
 #endif
 typedef const __attribute__((address_space(4))) uint32_t *r1_kargs_ptr;
+static_assert(sizeof(R1TraceArgs) % 4 == 0 && __is_trivially_copyable(R1TraceArgs), "fresh_args copies the argument block word by word");
 union R1ArgWords
 {
     R1TraceArgs a;
