@@ -1669,7 +1669,11 @@ struct TraceWaves
 #ifndef R1_TREE_WAVES_TP
 #define R1_TREE_WAVES_TP 7
 #endif
-    static constexpr int value = STATS ? 1 : (VARIANT == 4 ? (BIG ? 8 : ((MODE == 0 || MODE == 3) ? R1_TREE_WAVES_TP : 6)) : (VARIANT == 2 && !BIG ? 5 : 1));
+#ifndef R1_TREE_WAVES_LAT
+#define R1_TREE_WAVES_LAT 6 // (the synchronous build: 67 VGPRs, seven workgroups per CU at run time; built for eight — 64 VGPRs, two words of the
+                            //  LDS stack less — it spills and is no faster: profiles/r04/retune_after_fresh_args.txt)
+#endif
+    static constexpr int value = STATS ? 1 : (VARIANT == 4 ? (BIG ? 8 : ((MODE == 0 || MODE == 3) ? R1_TREE_WAVES_TP : R1_TREE_WAVES_LAT)) : (VARIANT == 2 && !BIG ? 5 : 1));
 };
 
 // MODE 1 = LAT = latency-mode build (the synchronous entry points: one frame, full grid): sub-queues and
